@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: cosine top-100 queries/s over a 10M x 768 bf16 corpus resident in HBM.
+
+A "step" is one 64-query batch searched against this rank's corpus shard (BASELINE.json configs[2]:
+"1xMI355X: 10Mx768 bf16 corpus resident in HBM, batch-64 queries").  With N ranks every rank holds its
+own 10M-row shard (weak scaling, configs[3]); a step additionally all-gathers the N local top-100
+lists over RCCL and merges them on every rank.  `value` counts (query, 10M-row shard) scans per second
+over all ranks, i.e. row.query pairs/s / 1e7.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  No reference code or CPU path is inside the timed region; the CPU
+baseline leg (oracle, test infrastructure) runs afterwards on rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per GPU")
+    ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--seed-tiles", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-rows", type=int, default=200_000, help="rows of the parity subsample checked vs the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd import ffi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    D, N, B, K = 768, args.rows, args.queries, args.k
+    dtype = ffi.DTYPE_BF16 if args.dtype == "bf16" else ffi.DTYPE_F32
+    elem = 2  # the scan always streams the bf16 tiled copy
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic corpus, generated on the device in blocks (never staged through host lists)
+    idx = ffi.Index(D, dtype, capacity_rows=N, device=local_rank)
+    if args.seed_tiles:
+        idx.set_tuning(seed_tiles=args.seed_tiles)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20251226 + rank)
+    block = 500_000
+    head = None
+    for r0 in range(0, N, block):
+        m = min(block, N - r0)
+        xb = torch.randn((m, D), generator=gen, device=dev, dtype=torch.float32)
+        idx.append(xb, stream=stream)
+        if r0 == 0:
+            head = xb[: min(args.check_rows, m)].cpu().numpy()
+        torch.cuda.synchronize()
+        del xb
+    qs = np.random.default_rng(7).standard_normal((B, D)).astype(np.float32)
+    qd = torch.from_numpy(qs).to(dev)
+    row_base = rank * N
+
+    nslots = 4
+    out_s = [torch.empty((B, K), dtype=torch.float32, device=dev) for _ in range(nslots)]
+    out_r = [torch.empty((B, K), dtype=torch.int64, device=dev) for _ in range(nslots)]
+    if world > 1:
+        gat_s = torch.empty((world, B, K), dtype=torch.float32, device=dev)
+        gat_r = torch.empty((world, B, K), dtype=torch.int64, device=dev)
+        mer_s = torch.empty((B, K), dtype=torch.float32, device=dev)
+        mer_r = torch.empty((B, K), dtype=torch.int64, device=dev)
+
+    def step(i: int) -> None:
+        s, r = out_s[i % nslots], out_r[i % nslots]
+        idx.search(qd, K, row_base=row_base, out_scores=s, out_rows=r, stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gat_s, s)
+            dist.all_gather_into_tensor(gat_r, r)
+            ffi.merge_topk(gat_s, gat_r, mer_s, mer_r, stream)
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    idx.search_finish(stream)
+    fence()
+    idx.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    idx.search_finish(stream)  # also verifies no candidate buffer overflowed in any timed step
+    fence()
+    dt = time.perf_counter() - t0
+    scan_ms_total, scan_launches = idx.profile()
+    idx.set_profiling(False)
+    stats = idx.stats()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- parity on a subsample (outside the timed region): first check_rows rows of rank 0 vs the oracle
+    parity = None
+    if rank == 0 and head is not None and args.check_rows > 0:
+        from oracle import search as orc
+        sub = ffi.Index(D, dtype, capacity_rows=head.shape[0], device=local_rank)
+        sub.append(head)
+        gs, gr = sub.search(qs, K)
+        es, er = orc.cosine_search(head, qs, K, bf16=(args.dtype == "bf16"))
+        truth_s, truth_r = orc.cosine_search(head, qs, K, bf16=False)
+        recall_same = float(np.mean([len(set(a) & set(b)) / K for a, b in zip(gr, er)]))
+        recall_f32 = float(np.mean([len(set(a) & set(b)) / K for a, b in zip(gr, truth_r)]))
+        parity = {"rows": int(head.shape[0]), "ids_bit_exact": bool(np.array_equal(gr, er)),
+                  "scores_bit_exact": bool(np.array_equal(gs.view(np.uint32), es.view(np.uint32))),
+                  "recall_at_k_vs_oracle_same_precision": recall_same, "recall_at_k_vs_f32_truth": recall_f32}
+        sub.close()
+
+    ms_per_step = dt * 1e3 / args.steps
+    value = world * B * args.steps / dt * (N / 1e7)
+    scan_ms = scan_ms_total / max(1, scan_launches)
+    alg_bytes = float(N) * D * elem
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    out = {
+        "metric": "top-k queries/s over 10Mx768 (cosine top-100, batch 64)",
+        "value": value,
+        "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 corpus/query, f32 accumulate" if args.dtype == "bf16" else "f32 store (bf16 scan + f32 canonical re-score)",
+        "data": "synthetic: N(0,I) rows generated on device (torch seed 20251226+rank), normalised on insert; queries numpy default_rng(7)",
+        "config": {"workload": f"{world}x MI355X: {N}x{D} {args.dtype} corpus per GPU resident in HBM, batch-{B} queries, exact top-{K}"
+                               + (", all-gather + merge of per-GPU top-k over RCCL" if world > 1 else ""),
+                   "rows_per_gpu": N, "dim": D, "batch": B, "k": K, "parallelism": f"row-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_scan<48,1,16,8>", "kernel_ms": scan_ms, "launches": scan_launches,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "search_stats": stats,
+        "parity": parity,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(np, B, K, D)
+    if rank == 0:
+        print(json.dumps(out))
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, B, K, D):
+    """Exact cosine top-k on the host cores with the oracle's BLAS scan (oracle/search.py:search_blas):
+    the stand-in for "Qdrant exact scan" (BASELINE.md section 3).  Bounded sample: 1M rows, ~10 s."""
+    from oracle import search as orc
+    rows = 1_000_000
+    rng = np.random.default_rng(20251226)
+    x = rng.standard_normal((rows, D), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = orc.preprocess(np.random.default_rng(7).standard_normal((B, D)).astype(np.float32))
+    orc.search_blas(x, q, K)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0:
+        orc.search_blas(x, q, K)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": B / dt * (rows / 1e7), "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7)",
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle BLAS exact scan (f32 sgemm + argpartition), {rows} rows x {B} queries top-{K}, "
+                      f"{reps} batches of {dt * 1e3:.0f} ms, scaled to 10M rows"}
+
+
+if __name__ == "__main__":
+    main()

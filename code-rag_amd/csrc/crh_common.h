@@ -1,0 +1,58 @@
+// crh_common.h -- shared host-side helpers for libcoderag_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/coderag_hip.h"
+
+namespace crh {
+
+std::string &last_error_ref();
+
+inline int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define CRH_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ::crh::fail(CRH_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define CRH_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != CRH_OK) return rc_; \
+    } while (0)
+
+// RAII guard: make `device` current for the duration of a call, restore on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace crh

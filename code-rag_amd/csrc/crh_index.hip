@@ -1,0 +1,733 @@
+// crh_index.hip -- host side of the HBM-resident cosine index behind include/coderag_hip.h.
+//
+// Replaces the Qdrant collection the reference talks to through
+// src/lattice/embeddings/client.py (QdrantManager): create / upsert / search / delete.
+// One handle = one collection shard on one GPU.  gfx950 only; no fallback path exists:
+// if HIP or the device is missing every entry point fails with CRH_E_HIP / CRH_E_NODEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "crh_common.h"
+#include "crh_kernels.hpp"
+
+namespace crh {
+std::string &last_error_ref()
+{
+    thread_local std::string s;
+    return s;
+}
+}  // namespace crh
+
+using namespace crh;
+
+namespace {
+
+constexpr int kWaves = 16;      // waves per scan workgroup (one workgroup per CU)
+constexpr int kRing = 8;        // 1-KiB loads in flight per wave
+constexpr int kStatusSlots = 1024;
+constexpr int64_t kWorkspaceBudget = 48LL << 30;
+
+struct Pending {
+    int nq, k, nfilt;
+    crh_filter filt[CRH_MAX_FILTERS];
+    int64_t row_base;
+    const float *q_dev;
+    float *out_s;
+    int64_t *out_r;
+    int slot;
+};
+
+}  // namespace
+
+struct crh_index {
+    int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
+    int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
+    u32x4 *xt = nullptr;
+    float *xf32 = nullptr;
+    uint32_t *alive = nullptr;
+    int32_t *codes = nullptr;
+    unsigned int *scratch_u32 = nullptr;
+
+    // tuning
+    int seed_tiles = 4096, wave_cap = 2048, qcap = 65536, force_fallback = 0;
+
+    // workspace (lazily sized)
+    int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
+    int64_t ws_mask_tiles = 0;
+    float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
+    u32x4 *qfrag = nullptr, *wave_lists = nullptr;
+    uint32_t *effmask = nullptr;
+    unsigned int *qcount = nullptr;
+    u32x2 *qlist = nullptr;
+    unsigned long long *skeys = nullptr;
+    SearchStatus *status = nullptr;
+    float *stage_q = nullptr;
+    int64_t stage_q_elems = 0;
+    float *stage_os = nullptr;
+    int64_t *stage_or = nullptr;
+    int64_t stage_out_elems = 0;
+    void *stage_in = nullptr;
+    int64_t stage_in_bytes = 0;
+
+    std::vector<Pending> pending;
+    int next_slot = 0;
+    crh_search_stats stats{};
+
+    // optional HIP-event timing of the dominant kernel (bench.py's roofline figure)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;  // 2 per status slot: before / after the main scan launch
+    double prof_scan_ms = 0.0;
+    int64_t prof_scan_launches = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, int64_t elems)
+{
+    *p = nullptr;
+    if (elems <= 0) return CRH_OK;
+    CRH_HIP(hipMalloc(reinterpret_cast<void **>(p), (size_t)elems * sizeof(T)));
+    return CRH_OK;
+}
+template <typename T>
+void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+float margin_for(const crh_index *h)
+{
+    // bound on |MFMA bf16 score - canonical score| for unit vectors, times 2 ("margin"):
+    //  bf16 store: both sums run over the same exact products; f32 accumulation error <= 768*2^-24 each
+    //  f32 store : + rounding q and x to bf16 for the scan, <= 2*2^-9 + 2^-18 by Cauchy-Schwarz
+    const float acc = 1.5e-4f;
+    return h->dtype == CRH_DTYPE_BF16 ? 2.f * acc : 2.f * (acc + 3.92e-3f);
+}
+
+int ensure_stage_in(crh_index *h, int64_t bytes)
+{
+    if (h->stage_in_bytes >= bytes) return CRH_OK;
+    if (h->stage_in) (void)hipFree(h->stage_in);
+    h->stage_in = nullptr;
+    h->stage_in_bytes = 0;
+    CRH_HIP(hipMalloc(&h->stage_in, (size_t)bytes));
+    h->stage_in_bytes = bytes;
+    return CRH_OK;
+}
+
+int scan_blocks(const crh_index *h, int64_t nitems)
+{
+    int64_t b = ceil_div(nitems, kWaves);
+    if (b > h->cu_count) b = h->cu_count;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// (re)allocate the search workspace for the current tuning
+int ensure_workspace(crh_index *h, int wave_cap, int qcap)
+{
+    const int blocks = h->cu_count;
+    if (!h->qn) {
+        CRH_TRY(dev_alloc(&h->qn, (int64_t)kMaxQ * h->dim));
+        CRH_TRY(dev_alloc(&h->qfrag, (int64_t)2 * h->ksteps * 64));
+        CRH_TRY(dev_alloc(&h->tau, kMaxQ));
+        CRH_TRY(dev_alloc(&h->qcount, kMaxQ));
+        CRH_TRY(dev_alloc(&h->status, kStatusSlots));
+    }
+    if (h->ws_seed < h->seed_tiles) {
+        dev_free(h->gmax);
+        CRH_TRY(dev_alloc(&h->gmax, (int64_t)h->seed_tiles * kMaxQ));
+        h->ws_seed = h->seed_tiles;
+    }
+    if (h->ws_mask_tiles < h->cap_tiles) {
+        dev_free(h->effmask);
+        CRH_TRY(dev_alloc(&h->effmask, h->cap_tiles));
+        h->ws_mask_tiles = h->cap_tiles;
+    }
+    if (h->ws_blocks != blocks || h->ws_wave_cap != wave_cap) {
+        const int64_t bytes = (int64_t)blocks * kWaves * wave_cap * 16;
+        if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "candidate workspace of %lld bytes exceeds the budget", (long long)bytes);
+        dev_free(h->wave_lists);
+        CRH_TRY(dev_alloc(&h->wave_lists, (int64_t)blocks * kWaves * wave_cap));
+        h->ws_blocks = blocks;
+        h->ws_wave_cap = wave_cap;
+    }
+    if (h->ws_qcap != qcap) {
+        const int64_t bytes = (int64_t)kMaxQ * qcap * 16;
+        if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "per-query candidate lists of %lld bytes exceed the budget", (long long)bytes);
+        dev_free(h->qlist);
+        dev_free(h->skeys);
+        CRH_TRY(dev_alloc(&h->qlist, (int64_t)kMaxQ * qcap));
+        CRH_TRY(dev_alloc(&h->skeys, (int64_t)kMaxQ * qcap));
+        h->ws_qcap = qcap;
+    }
+    return CRH_OK;
+}
+
+__global__ void k_fill_pad(float *s, int64_t *r, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        s[i] = -INFINITY;
+        r[i] = -1;
+    }
+}
+
+int build_mask(crh_index *h, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
+{
+    if (nfilt == 0) {
+        *mask_out = h->alive;
+        return CRH_OK;
+    }
+    FilterSet fs;
+    fs.n = nfilt;
+    for (int f = 0; f < nfilt; ++f) {
+        if (filters[f].col < 0 || filters[f].col >= h->ncols)
+            return fail(CRH_E_INVALID, "filter column %d out of range (index has %d code columns)", filters[f].col, h->ncols);
+        fs.col[f] = filters[f].col;
+        fs.code[f] = filters[f].code;
+    }
+    const int64_t rows = (h->count + 63) & ~63LL;
+    hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, h->alive, h->codes, h->cap_rows,
+                       h->count, fs, h->effmask);
+    CRH_HIP(hipGetLastError());
+    *mask_out = h->effmask;
+    return CRH_OK;
+}
+
+// one <= 64-query batch, everything enqueued on `st`
+int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
+                  int64_t *out_r, int slot, hipStream_t st)
+{
+    const int64_t ntiles = ceil_div(h->count, kTileRows);
+    if (ntiles == 0) {
+        const int64_t n = (int64_t)nq * k;
+        hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out_s, out_r, n);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
+    const int wave_cap = h->ws_wave_cap, qcap = h->ws_qcap;
+    const float margin = margin_for(h);
+    SearchStatus *stt = h->status + slot;
+    CRH_HIP(hipMemsetAsync(h->qcount, 0, kMaxQ * sizeof(unsigned int), st));
+    CRH_HIP(hipMemsetAsync(stt, 0, sizeof(SearchStatus), st));
+
+    if (h->dtype == CRH_DTYPE_BF16)
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(kMaxQ), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+    else
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(kMaxQ), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+    CRH_HIP(hipGetLastError());
+
+    const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
+    const int stride = (int)(ntiles / G);
+    hipLaunchKernelGGL((k_scan<48, 0, kWaves, kRing>), dim3(scan_blocks(h, G)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
+                       h->tau, mask, G, stride, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt);
+    CRH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_tau, dim3(kMaxQ), dim3(256), 0, st, h->gmax, G, k, margin, h->tau);
+    CRH_HIP(hipGetLastError());
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
+    hipLaunchKernelGGL((k_scan<48, 1, kWaves, kRing>), dim3(scan_blocks(h, ntiles)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
+                       h->tau, mask, (int)ntiles, 1, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt);
+    CRH_HIP(hipGetLastError());
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
+    if (h->dtype == CRH_DTYPE_F32)
+        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, h->qcount, qcap, h->skeys, h->qn, h->xt,
+                           h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+    else
+        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, h->qlist, h->qcount, qcap, h->skeys, h->qn, h->xt,
+                           h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+    CRH_HIP(hipGetLastError());
+    h->stats.rows += h->count;
+    h->stats.tiles += ntiles;
+    h->stats.seed_tiles += G;
+    h->stats.batches += 1;
+    return CRH_OK;
+}
+
+int next_pow2(int64_t v)
+{
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return (int)std::min<int64_t>(p, 1LL << 30);
+}
+
+int finish_pending(crh_index *h, hipStream_t st)
+{
+    if (h->pending.empty()) return CRH_OK;
+    CRH_HIP(hipStreamSynchronize(st));
+    std::vector<SearchStatus> host(kStatusSlots);
+    CRH_HIP(hipMemcpy(host.data(), h->status, sizeof(SearchStatus) * kStatusSlots, hipMemcpyDeviceToHost));
+    std::vector<Pending> todo;
+    todo.swap(h->pending);
+    h->next_slot = 0;
+    for (const Pending &p : todo) {
+        SearchStatus s = host[p.slot];
+        if (h->profiling && h->count > 0) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[2 * p.slot], h->ev[2 * p.slot + 1]) == hipSuccess) {
+                h->prof_scan_ms += ms;
+                h->prof_scan_launches += 1;
+            }
+        }
+        int attempts = 0;
+        while (s.wave_overflow || s.q_overflow) {
+            if (++attempts > 4) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
+            h->stats.fallback_used = 1;
+            const int wc = std::max(h->ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
+            const int qc = std::max(h->ws_qcap, next_pow2((int64_t)s.max_qcount));
+            CRH_TRY(ensure_workspace(h, wc, qc));
+            const uint32_t *mask = nullptr;
+            CRH_TRY(build_mask(h, p.filt, p.nfilt, &mask, st));
+            CRH_TRY(enqueue_batch(h, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st));
+            CRH_HIP(hipStreamSynchronize(st));
+            CRH_HIP(hipMemcpy(&s, h->status, sizeof(SearchStatus), hipMemcpyDeviceToHost));
+        }
+        h->stats.candidates += (int64_t)s.candidates;
+        h->stats.max_query_cands = std::max<int64_t>(h->stats.max_query_cands, s.max_qcount);
+    }
+    return CRH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crh_abi_version(void) { return CRH_ABI_VERSION; }
+const char *crh_last_error(void) { return last_error_ref().c_str(); }
+
+int crh_device_count(int *count)
+{
+    if (!count) return fail(CRH_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(CRH_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return CRH_OK;
+}
+
+int crh_device_info(int device, char *name_out, int name_cap, char *arch_out, int arch_cap, int64_t *hbm_bytes_out,
+                    int *cu_count_out)
+{
+    hipDeviceProp_t prop;
+    CRH_HIP(hipGetDeviceProperties(&prop, device));
+    if (name_out && name_cap > 0) snprintf(name_out, (size_t)name_cap, "%s", prop.name);
+    if (arch_out && arch_cap > 0) snprintf(arch_out, (size_t)arch_cap, "%s", prop.gcnArchName);
+    if (hbm_bytes_out) *hbm_bytes_out = (int64_t)prop.totalGlobalMem;
+    if (cu_count_out) *cu_count_out = prop.multiProcessorCount;
+    return CRH_OK;
+}
+
+int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols, int device, crh_index **out)
+{
+    if (!out) return fail(CRH_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dim != 768) return fail(CRH_E_INVALID, "dim %d not supported: the scan kernel is built for dim 768 (UniXcoder)", dim);
+    if (dtype != CRH_DTYPE_F32 && dtype != CRH_DTYPE_BF16) return fail(CRH_E_INVALID, "unknown dtype %d", dtype);
+    if (capacity_rows <= 0 || capacity_rows > (1LL << 31)) return fail(CRH_E_INVALID, "capacity_rows %lld out of range", (long long)capacity_rows);
+    if (n_code_cols < 0 || n_code_cols > 64) return fail(CRH_E_INVALID, "n_code_cols %d out of range", n_code_cols);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CRH_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(CRH_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    CRH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CRH_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(CRH_E_HIP, "hipSetDevice(%d) failed", device);
+
+    crh_index *h = new crh_index();
+    h->dim = dim;
+    h->ksteps = dim / 16;
+    h->dtype = dtype;
+    h->ncols = n_code_cols;
+    h->device = device;
+    h->cu_count = prop.multiProcessorCount;
+    h->cap_rows = (capacity_rows + 31) & ~31LL;
+    h->cap_tiles = h->cap_rows / 32;
+    int rc = dev_alloc(&h->xt, h->cap_tiles * h->ksteps * 64);
+    if (rc == CRH_OK && dtype == CRH_DTYPE_F32) rc = dev_alloc(&h->xf32, h->cap_rows * dim);
+    if (rc == CRH_OK) rc = dev_alloc(&h->alive, h->cap_tiles);
+    if (rc == CRH_OK && n_code_cols) rc = dev_alloc(&h->codes, h->cap_rows * n_code_cols);
+    if (rc == CRH_OK) rc = dev_alloc(&h->scratch_u32, 4);
+    if (rc == CRH_OK && hipMemset(h->xt, 0, (size_t)h->cap_tiles * h->ksteps * 1024) != hipSuccess) rc = fail(CRH_E_HIP, "hipMemset(xt) failed");
+    if (rc == CRH_OK && hipMemset(h->alive, 0, (size_t)h->cap_tiles * 4) != hipSuccess) rc = fail(CRH_E_HIP, "hipMemset(alive) failed");
+    if (rc == CRH_OK && h->codes && hipMemset(h->codes, 0xff, (size_t)h->cap_rows * n_code_cols * 4) != hipSuccess)
+        rc = fail(CRH_E_HIP, "hipMemset(codes) failed");
+    if (rc != CRH_OK) {
+        crh_index_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return CRH_OK;
+}
+
+int crh_index_destroy(crh_index *h)
+{
+    if (!h) return CRH_OK;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    dev_free(h->xt);
+    dev_free(h->xf32);
+    dev_free(h->alive);
+    dev_free(h->codes);
+    dev_free(h->scratch_u32);
+    dev_free(h->qn);
+    dev_free(h->gmax);
+    dev_free(h->tau);
+    dev_free(h->qfrag);
+    dev_free(h->wave_lists);
+    dev_free(h->effmask);
+    dev_free(h->qcount);
+    dev_free(h->qlist);
+    dev_free(h->skeys);
+    dev_free(h->status);
+    dev_free(h->stage_q);
+    dev_free(h->stage_os);
+    dev_free(h->stage_or);
+    if (h->stage_in) (void)hipFree(h->stage_in);
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+    return CRH_OK;
+}
+
+int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device, const int32_t *codes, int64_t *first_row_out,
+                     void *stream)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (n < 0) return fail(CRH_E_INVALID, "n < 0");
+    if (first_row_out) *first_row_out = h->count;
+    if (n == 0) return CRH_OK;
+    if (!vecs) return fail(CRH_E_INVALID, "vecs is NULL");
+    if (h->ncols > 0 && !codes) return fail(CRH_E_INVALID, "index has %d code columns but codes is NULL", h->ncols);
+    if (h->count + n > h->cap_rows)
+        return fail(CRH_E_CAPACITY, "append of %lld rows exceeds capacity (%lld of %lld used)", (long long)n, (long long)h->count,
+                    (long long)h->cap_rows);
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t chunk = 65536;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        const float *src = vecs + off * h->dim;
+        const int32_t *csrc = codes ? codes + off * h->ncols : nullptr;
+        if (!on_device) {
+            const int64_t vb = m * h->dim * 4, cb = m * h->ncols * 4;
+            CRH_TRY(ensure_stage_in(h, vb + cb));
+            CRH_HIP(hipMemcpyAsync(h->stage_in, src, (size_t)vb, hipMemcpyHostToDevice, st));
+            src = static_cast<const float *>(h->stage_in);
+            if (csrc) {
+                void *cd = static_cast<char *>(h->stage_in) + vb;
+                CRH_HIP(hipMemcpyAsync(cd, csrc, (size_t)cb, hipMemcpyHostToDevice, st));
+                csrc = static_cast<const int32_t *>(cd);
+            }
+        }
+        const int64_t first = h->count + off;
+        const unsigned blocks = (unsigned)ceil_div(m, 32);
+        if (h->dtype == CRH_DTYPE_F32)
+            hipLaunchKernelGGL(k_append<true>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32);
+        else
+            hipLaunchKernelGGL(k_append<false>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32);
+        CRH_HIP(hipGetLastError());
+        if (csrc) {
+            hipLaunchKernelGGL(k_store_codes, dim3((unsigned)ceil_div(m * h->ncols, 256)), dim3(256), 0, st, csrc, m, h->ncols, first,
+                               h->cap_rows, h->codes);
+            CRH_HIP(hipGetLastError());
+        }
+        const int64_t ntl = ((first + m - 1) >> 5) - (first >> 5) + 1;
+        hipLaunchKernelGGL(k_set_alive, dim3((unsigned)ceil_div(ntl, 256)), dim3(256), 0, st, h->alive, first, m);
+        CRH_HIP(hipGetLastError());
+        if (!on_device) CRH_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
+    }
+    h->count += n;
+    h->alive_count += n;
+    return CRH_OK;
+}
+
+int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (n <= 0) return CRH_OK;
+    if (!rows) return fail(CRH_E_INVALID, "rows is NULL");
+    DeviceGuard g(h->device);
+    CRH_TRY(ensure_stage_in(h, n * 8));
+    CRH_HIP(hipMemcpy(h->stage_in, rows, (size_t)n * 8, hipMemcpyHostToDevice));
+    CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
+    hipLaunchKernelGGL(k_tombstone, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, 0, h->alive,
+                       static_cast<const int64_t *>(h->stage_in), n, h->count, h->scratch_u32);
+    CRH_HIP(hipGetLastError());
+    unsigned int cleared = 0;
+    CRH_HIP(hipMemcpy(&cleared, h->scratch_u32, 4, hipMemcpyDeviceToHost));
+    h->alive_count -= cleared;
+    return CRH_OK;
+}
+
+int crh_index_count(crh_index *h, int64_t *rows_out, int64_t *alive_out)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (rows_out) *rows_out = h->count;
+    if (alive_out) *alive_out = h->alive_count;
+    return CRH_OK;
+}
+
+int crh_index_clear(crh_index *h)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());
+    const int64_t used_tiles = ceil_div(h->count, 32);
+    if (used_tiles) {
+        CRH_HIP(hipMemset(h->xt, 0, (size_t)used_tiles * h->ksteps * 1024));
+        CRH_HIP(hipMemset(h->alive, 0, (size_t)used_tiles * 4));
+    }
+    h->count = 0;
+    h->alive_count = 0;
+    h->pending.clear();
+    h->next_slot = 0;
+    return CRH_OK;
+}
+
+int crh_index_reserve(crh_index *h, int64_t capacity_rows)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (capacity_rows <= h->cap_rows) return CRH_OK;
+    if (capacity_rows > (1LL << 31)) return fail(CRH_E_INVALID, "capacity_rows %lld out of range", (long long)capacity_rows);
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());
+    const int64_t new_rows = (capacity_rows + 31) & ~31LL, new_tiles = new_rows / 32;
+    const int64_t used_tiles = ceil_div(h->count, 32);
+    u32x4 *nxt = nullptr;
+    float *nf32 = nullptr;
+    uint32_t *nalive = nullptr;
+    int32_t *ncodes = nullptr;
+    int rc = dev_alloc(&nxt, new_tiles * h->ksteps * 64);
+    if (rc == CRH_OK && h->xf32) rc = dev_alloc(&nf32, new_rows * h->dim);
+    if (rc == CRH_OK) rc = dev_alloc(&nalive, new_tiles);
+    if (rc == CRH_OK && h->ncols) rc = dev_alloc(&ncodes, new_rows * h->ncols);
+    hipError_t e = hipSuccess;
+    if (rc == CRH_OK) {
+        const size_t used_b = (size_t)used_tiles * h->ksteps * 1024;
+        if (e == hipSuccess) e = hipMemset(reinterpret_cast<char *>(nxt) + used_b, 0, (size_t)new_tiles * h->ksteps * 1024 - used_b);
+        if (e == hipSuccess && used_b) e = hipMemcpy(nxt, h->xt, used_b, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemset(nalive, 0, (size_t)new_tiles * 4);
+        if (e == hipSuccess && used_tiles) e = hipMemcpy(nalive, h->alive, (size_t)used_tiles * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && nf32 && h->count) e = hipMemcpy(nf32, h->xf32, (size_t)h->count * h->dim * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && ncodes) e = hipMemset(ncodes, 0xff, (size_t)new_rows * h->ncols * 4);
+        for (int c = 0; c < h->ncols && e == hipSuccess && h->count; ++c)
+            e = hipMemcpy(ncodes + (int64_t)c * new_rows, h->codes + (int64_t)c * h->cap_rows, (size_t)h->count * 4, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) rc = fail(CRH_E_HIP, "reserve copy failed: %s", hipGetErrorString(e));
+    }
+    if (rc != CRH_OK) {
+        dev_free(nxt);
+        dev_free(nf32);
+        dev_free(nalive);
+        dev_free(ncodes);
+        return rc;
+    }
+    dev_free(h->xt);
+    dev_free(h->xf32);
+    dev_free(h->alive);
+    dev_free(h->codes);
+    h->xt = nxt;
+    h->xf32 = nf32;
+    h->alive = nalive;
+    h->codes = ncodes;
+    h->cap_rows = new_rows;
+    h->cap_tiles = new_tiles;
+    return CRH_OK;
+}
+
+int crh_index_read_rows(crh_index *h, int64_t first, int64_t n, float *out_host)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (first < 0 || n < 0 || first + n > h->count) return fail(CRH_E_INVALID, "row range [%lld,+%lld) outside the index", (long long)first, (long long)n);
+    if (n == 0) return CRH_OK;
+    if (!out_host) return fail(CRH_E_INVALID, "out_host is NULL");
+    DeviceGuard g(h->device);
+    if (h->dtype == CRH_DTYPE_F32) {
+        CRH_HIP(hipMemcpy(out_host, h->xf32 + first * h->dim, (size_t)n * h->dim * 4, hipMemcpyDeviceToHost));
+        return CRH_OK;
+    }
+    const int64_t chunk = 65536;
+    CRH_TRY(ensure_stage_in(h, std::min(chunk, n) * h->dim * 4));
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        hipLaunchKernelGGL(k_untile_rows, dim3((unsigned)ceil_div(m * (h->dim / 8), 256)), dim3(256), 0, 0, h->xt, h->ksteps,
+                           first + off, m, h->dim, static_cast<float *>(h->stage_in));
+        CRH_HIP(hipGetLastError());
+        CRH_HIP(hipMemcpy(out_host + off * h->dim, h->stage_in, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost));
+    }
+    return CRH_OK;
+}
+
+int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (seed_tiles > 0) h->seed_tiles = seed_tiles;
+    if (wave_cand_cap > 0) h->wave_cap = wave_cand_cap;
+    if (query_cand_cap > 0) h->qcap = query_cand_cap;
+    if (force_fallback >= 0) h->force_fallback = force_fallback;
+    return CRH_OK;
+}
+
+int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device, int k, const crh_filter *filters, int n_filters,
+               int64_t row_base, float *out_scores, int64_t *out_rows, int out_on_device, void *stream)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (nq < 0) return fail(CRH_E_INVALID, "nq < 0");
+    if (nq == 0) return CRH_OK;
+    if (!queries || !out_scores || !out_rows) return fail(CRH_E_INVALID, "NULL query or output pointer");
+    if (k <= 0 || k > CRH_MAX_K) return fail(CRH_E_CAPACITY, "k=%d outside 1..%d", k, CRH_MAX_K);
+    if (n_filters < 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 0..%d", n_filters, CRH_MAX_FILTERS);
+    if (n_filters > 0 && !filters) return fail(CRH_E_INVALID, "filters is NULL");
+    DeviceGuard g(h->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    // force_fallback (testing): start from absurdly small candidate buffers so the regrow-and-rerun path runs
+    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->ws_wave_cap);
+    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->ws_qcap);
+    CRH_TRY(ensure_workspace(h, wc, qc));
+
+    const float *q_dev = queries;
+    if (!queries_on_device) {
+        const int64_t elems = (int64_t)nq * h->dim;
+        if (h->stage_q_elems < elems) {
+            dev_free(h->stage_q);
+            CRH_TRY(dev_alloc(&h->stage_q, elems));
+            h->stage_q_elems = elems;
+        }
+        CRH_HIP(hipMemcpyAsync(h->stage_q, queries, (size_t)elems * 4, hipMemcpyHostToDevice, st));
+        q_dev = h->stage_q;
+    }
+    float *os = out_scores;
+    int64_t *orow = out_rows;
+    if (!out_on_device) {
+        const int64_t elems = (int64_t)nq * k;
+        if (h->stage_out_elems < elems) {
+            dev_free(h->stage_os);
+            dev_free(h->stage_or);
+            CRH_TRY(dev_alloc(&h->stage_os, elems));
+            CRH_TRY(dev_alloc(&h->stage_or, elems));
+            h->stage_out_elems = elems;
+        }
+        os = h->stage_os;
+        orow = h->stage_or;
+    }
+    if (h->pending.empty()) h->stats = crh_search_stats{};
+
+    const uint32_t *mask = nullptr;
+    CRH_TRY(build_mask(h, filters, n_filters, &mask, st));
+    for (int q0 = 0; q0 < nq; q0 += kMaxQ) {
+        const int b = std::min(kMaxQ, nq - q0);
+        if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
+        Pending p{};
+        p.nq = b;
+        p.k = k;
+        p.nfilt = n_filters;
+        for (int f = 0; f < n_filters; ++f) p.filt[f] = filters[f];
+        p.row_base = row_base;
+        p.q_dev = q_dev + (int64_t)q0 * h->dim;
+        p.out_s = os + (int64_t)q0 * k;
+        p.out_r = orow + (int64_t)q0 * k;
+        p.slot = h->next_slot++;
+        CRH_TRY(enqueue_batch(h, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
+        h->pending.push_back(p);
+        // a filtered search whose mask lives in the shared effmask buffer must complete before the next call
+        // rebuilds that buffer; the stream orders that for us.
+    }
+    if (!out_on_device || !queries_on_device) {
+        CRH_TRY(finish_pending(h, st));
+        if (!out_on_device) {
+            CRH_HIP(hipMemcpy(out_scores, h->stage_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+            CRH_HIP(hipMemcpy(out_rows, h->stage_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    return CRH_OK;
+}
+
+int crh_search_finish(crh_index *h, void *stream)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    return finish_pending(h, static_cast<hipStream_t>(stream));
+}
+
+int crh_index_set_profiling(crh_index *h, int enable)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    if (enable && h->ev.empty()) {
+        h->ev.resize(2 * kStatusSlots);
+        for (auto &e : h->ev) CRH_HIP(hipEventCreate(&e));
+    }
+    h->profiling = enable != 0;
+    h->prof_scan_ms = 0.0;
+    h->prof_scan_launches = 0;
+    return CRH_OK;
+}
+
+int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_launches)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (scan_ms_total) *scan_ms_total = h->prof_scan_ms;
+    if (scan_launches) *scan_launches = h->prof_scan_launches;
+    return CRH_OK;
+}
+
+int crh_search_get_stats(crh_index *h, crh_search_stats *out)
+{
+    if (!h || !out) return fail(CRH_E_INVALID, "NULL argument");
+    *out = h->stats;
+    return CRH_OK;
+}
+
+int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev, float *out_scores_dev,
+                   int64_t *out_rows_dev, void *stream)
+{
+    if (nlists <= 0 || nq < 0 || k <= 0) return fail(CRH_E_INVALID, "bad merge shape nlists=%d nq=%d k=%d", nlists, nq, k);
+    if (nq == 0) return CRH_OK;
+    if (!scores_dev || !rows_dev || !out_scores_dev || !out_rows_dev) return fail(CRH_E_INVALID, "NULL pointer");
+    const int total = nlists * k;
+    if (total > 8192) return fail(CRH_E_CAPACITY, "nlists*k=%d exceeds 8192", total);
+    int P = 1;
+    while (P < total) P <<= 1;
+    const size_t lds = (size_t)P * 4 + 8 + (size_t)P * 8;
+    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), lds, static_cast<hipStream_t>(stream), nlists, nq, k, scores_dev, rows_dev,
+                       out_scores_dev, out_rows_dev);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters, int64_t limit, int64_t *rows_out_host, int64_t *n_out)
+{
+    if (!h || !n_out) return fail(CRH_E_INVALID, "NULL argument");
+    *n_out = 0;
+    if (limit <= 0 || h->count == 0) return CRH_OK;
+    if (!rows_out_host) return fail(CRH_E_INVALID, "rows_out_host is NULL");
+    if (n_filters < 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 0..%d", n_filters, CRH_MAX_FILTERS);
+    DeviceGuard g(h->device);
+    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    const uint32_t *mask = nullptr;
+    CRH_TRY(build_mask(h, filters, n_filters, &mask, nullptr));
+    const int64_t ntiles = ceil_div(h->count, 32);
+    std::vector<uint32_t> hm((size_t)ntiles);
+    CRH_HIP(hipMemcpy(hm.data(), mask, (size_t)ntiles * 4, hipMemcpyDeviceToHost));
+    int64_t found = 0;
+    for (int64_t t = 0; t < ntiles && found < limit; ++t) {
+        uint32_t m = hm[(size_t)t];
+        while (m && found < limit) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            rows_out_host[found++] = t * 32 + b;
+        }
+    }
+    *n_out = found;
+    return CRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,743 @@
+// crh_kernels.cuh -- device code of the HBM-resident cosine index (gfx950 / CDNA4 only).
+//
+// Replaces what runs inside the Qdrant server for the reference's
+// QdrantManager.upsert / .search (src/lattice/embeddings/client.py:115-157):
+// normalise on insert, score = dot of normalised vectors, top-k descending.
+//
+// HBM layout of the corpus ("tiled bf16"): rows are grouped in tiles of 32; one tile holds
+// KSTEPS = dim/16 pieces of 1 KiB; piece s is exactly the A operand of one
+// v_mfma_f32_32x32x16_bf16 for k = 16s..16s+15: lane l = 32h + r holds the 8 bf16
+// X[32*tile + r][16s + 8h + 0..7].  A wave therefore streams a tile with 1-KiB fully
+// coalesced dwordx4 loads, straight into MFMA operand registers -- no LDS round trip,
+// no transposition, every HBM byte fetched exactly once.  The (<= 64) queries sit in LDS
+// in the matching B-operand layout for the whole kernel.
+//
+// Everything that decides a returned id or score is "canonical" f32 arithmetic: products
+// and sums rounded separately, in index order, exactly as oracle/search_oracle.c does.
+// The MFMA scan only nominates candidates; it never decides an order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kTileRows = 32;
+constexpr int kMaxQ = 64;  // queries per scan pass (two 32-column MFMA B blocks)
+
+struct SearchStatus {
+    unsigned int max_wave_cnt;  // largest per-wave candidate count (unclamped)
+    unsigned int max_qcount;    // largest per-query candidate count (unclamped)
+    unsigned int wave_overflow;
+    unsigned int q_overflow;
+    unsigned long long candidates;
+    unsigned long long pad_;
+};
+
+// ------------------------------------------------------------------ small helpers
+
+__device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// f32 -> bf16 bits, round to nearest even; NaN quieted (same integer recipe as the oracle's
+// orc_bf16_round so that the stored corpus is bit-identical).
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x)
+{
+    uint32_t u = f32_bits(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return ((u | 0x00400000u) >> 16);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_f32(uint32_t b) { return bits_f32(b << 16); }
+
+// order-preserving map f32 -> u32 (larger float <=> larger uint); no NaNs reach it.
+__device__ __forceinline__ uint32_t ord_f32(float f)
+{
+    uint32_t u = f32_bits(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return bits_f32(u);
+}
+
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+// address (in u32x4 units) of piece (tile, s) lane (h, r)
+__device__ __forceinline__ size_t tiled_index(int64_t tile, int ksteps, int s, int h, int r)
+{
+    return ((size_t)tile * ksteps + s) * 64 + (h * 32 + r);
+}
+
+// ------------------------------------------------------------------ append / preprocess
+
+// Qdrant cosine_preprocess for one vector whose squared length is already summed.
+// Returns the divisor (0 = leave unchanged).
+__device__ __forceinline__ float cosine_divisor(float len2)
+{
+    if (len2 < 1.1920928955078125e-07f || fabsf(len2 - 1.0f) <= 1.0e-6f) return 0.0f;
+    return __fsqrt_rn(len2);
+}
+
+// 32 rows per block, 256 threads.  src: raw f32 [n][dim]; rows land at first_row + i.
+template <bool KEEP_F32>
+__global__ __launch_bounds__(256) void k_append(const float *__restrict__ src, int64_t n, int64_t first_row,
+                                                int dim, int ksteps, u32x4 *__restrict__ xt,
+                                                float *__restrict__ xf32)
+{
+    __shared__ float buf[32][65];
+    __shared__ float divisor[32];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int nrows = (int)((n - row0) < 32 ? (n - row0) : 32);
+
+    float acc = 0.0f;  // threads 0..31: running squared length of row tid, index order
+    for (int kc = 0; kc < dim; kc += 64) {
+        for (int e = tid; e < 32 * 64; e += 256) {
+            int r = e >> 6, c = e & 63;
+            buf[r][c] = (r < nrows) ? src[(row0 + r) * dim + kc + c] : 0.0f;
+        }
+        __syncthreads();
+        if (tid < 32) {
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) {
+                float v = buf[tid][c];
+                float p = v * v;
+                acc = acc + p;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 32) divisor[tid] = cosine_divisor(acc);
+    __syncthreads();
+
+    const int chunks = dim >> 3;  // 16-byte bf16 chunks per row
+    for (int item = tid; item < chunks * 32; item += 256) {
+        int r = item & 31, c8 = item >> 5;
+        if (r >= nrows) continue;
+        const float4 *sp = reinterpret_cast<const float4 *>(src + (row0 + r) * dim + c8 * 8);
+        float4 a = sp[0], b = sp[1];
+        float dv = divisor[r];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (dv != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __fdiv_rn(v[j], dv);
+        }
+        int64_t gr = first_row + row0 + r;
+        if (KEEP_F32) {
+            float4 *dp = reinterpret_cast<float4 *>(xf32 + gr * dim + c8 * 8);
+            dp[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dp[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        u32x4 pk;
+        pk.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+        pk.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+        pk.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+        pk.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+        xt[tiled_index(gr >> 5, ksteps, c8 >> 1, c8 & 1, (int)(gr & 31))] = pk;
+    }
+}
+
+// alive[tile] |= bits of rows [first, first+n)
+__global__ void k_set_alive(uint32_t *alive, int64_t first, int64_t n)
+{
+    int64_t t0 = first >> 5, t1 = (first + n - 1) >> 5;
+    int64_t t = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > t1) return;
+    int lo = (t == t0) ? (int)(first & 31) : 0;
+    int hi = (t == t1) ? (int)((first + n - 1) & 31) : 31;
+    uint32_t m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+    alive[t] |= m;
+}
+
+// codes_in [n][ncols] -> codes [ncols][cap_rows] at first_row
+__global__ void k_store_codes(const int32_t *__restrict__ in, int64_t n, int ncols, int64_t first_row,
+                              int64_t cap_rows, int32_t *__restrict__ codes)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ncols) return;
+    int64_t r = i / ncols;
+    int c = (int)(i % ncols);
+    codes[(int64_t)c * cap_rows + first_row + r] = in[i];
+}
+
+__global__ void k_tombstone(uint32_t *alive, const int64_t *__restrict__ rows, int64_t n, int64_t count,
+                            unsigned int *cleared)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t r = rows[i];
+    if (r < 0 || r >= count) return;
+    uint32_t bit = 1u << (r & 31);
+    uint32_t old = atomicAnd(&alive[r >> 5], ~bit);
+    if (old & bit) atomicAdd(cleared, 1u);
+}
+
+// effective row mask of a filtered search: alive AND every (col == code).  One thread per row.
+struct FilterSet {
+    int n;
+    int col[CRH_MAX_FILTERS];
+    int code[CRH_MAX_FILTERS];
+};
+__global__ __launch_bounds__(256) void k_filter_mask(const uint32_t *__restrict__ alive,
+                                                     const int32_t *__restrict__ codes, int64_t cap_rows,
+                                                     int64_t count, FilterSet fs, uint32_t *__restrict__ out)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = r < count;
+    if (ok) {
+        for (int f = 0; f < fs.n; ++f) ok = ok && (codes[(int64_t)fs.col[f] * cap_rows + r] == fs.code[f]);
+    }
+    unsigned long long b = __ballot(ok);
+    int lane = lane_id();
+    int64_t tile = r >> 5;
+    if ((lane & 31) == 0 && (tile << 5) < ((count + 31) & ~31LL)) {
+        uint32_t m = (uint32_t)(lane ? (b >> 32) : b);
+        out[tile] = m & alive[tile];
+    }
+}
+
+// untile rows [first, first+n) into f32 [n][dim] (the bf16 copy; exact bf16 values)
+__global__ void k_untile_rows(const u32x4 *__restrict__ xt, int ksteps, int64_t first, int64_t n, int dim,
+                              float *__restrict__ out)
+{
+    int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int chunks = dim >> 3;
+    if (item >= n * chunks) return;
+    int64_t i = item / chunks;
+    int c8 = (int)(item % chunks);
+    int64_t gr = first + i;
+    u32x4 pk = xt[tiled_index(gr >> 5, ksteps, c8 >> 1, c8 & 1, (int)(gr & 31))];
+    float *o = out + i * dim + c8 * 8;
+    o[0] = bf16_bits_f32(pk.x & 0xffffu);
+    o[1] = bf16_bits_f32(pk.x >> 16);
+    o[2] = bf16_bits_f32(pk.y & 0xffffu);
+    o[3] = bf16_bits_f32(pk.y >> 16);
+    o[4] = bf16_bits_f32(pk.z & 0xffffu);
+    o[5] = bf16_bits_f32(pk.z >> 16);
+    o[6] = bf16_bits_f32(pk.w & 0xffffu);
+    o[7] = bf16_bits_f32(pk.w >> 16);
+}
+
+// ------------------------------------------------------------------ query preparation
+
+// One block (64 threads) per query slot 0..63.  Slots >= nq become all-zero queries.
+// qn:    [64][dim] f32 -- the canonical query the rescoring uses: cosine_preprocess(q), and for a
+//        bf16 store additionally rounded to bf16 (what the oracle scores with).
+// qfrag: [2][ksteps][64] u32x4 -- bf16 B-operand pieces for the scan.
+template <bool ROUND_BF16>
+__global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q, int nq, int dim, int ksteps,
+                                                     float *__restrict__ qn, u32x4 *__restrict__ qfrag)
+{
+    __shared__ float dv_s;
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const bool real = qi < nq;
+    const float *src = q + (int64_t)qi * dim;
+    if (tid == 0) {
+        float acc = 0.0f;
+        if (real)
+            for (int i = 0; i < dim; ++i) {
+                float v = src[i];
+                float p = v * v;
+                acc = acc + p;
+            }
+        dv_s = cosine_divisor(acc);
+    }
+    __syncthreads();
+    const float dv = dv_s;
+    const int qb = qi >> 5, c = qi & 31;
+    for (int c8 = tid; c8 < (dim >> 3); c8 += 64) {
+        float v[8];
+        uint32_t hb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = real ? src[c8 * 8 + j] : 0.0f;
+            if (dv != 0.0f) x = __fdiv_rn(x, dv);
+            hb[j] = f32_to_bf16_bits(x);
+            v[j] = ROUND_BF16 ? bf16_bits_f32(hb[j]) : x;
+            qn[(int64_t)qi * dim + c8 * 8 + j] = v[j];
+        }
+        u32x4 pk;
+        pk.x = hb[0] | (hb[1] << 16);
+        pk.y = hb[2] | (hb[3] << 16);
+        pk.z = hb[4] | (hb[5] << 16);
+        pk.w = hb[6] | (hb[7] << 16);
+        qfrag[((size_t)qb * ksteps + (c8 >> 1)) * 64 + ((c8 & 1) * 32 + c)] = pk;
+    }
+}
+
+// ------------------------------------------------------------------ the scan
+
+// MODE 0 (seed):  items are sample tiles; writes gmax[item][q] = max over the tile's valid rows.
+// MODE 1 (main):  items are all tiles; rows with score >= tau[q] become candidates.
+//
+// One workgroup per CU (the 96 KB query image pins that), WAVES waves each streaming its own
+// tiles: item i of wave g is i = g + j*total_waves.  Per k-step a wave issues one 1-KiB
+// nontemporal load (RING of them in flight, running ahead across tile boundaries), reads two
+// 1-KiB query pieces from LDS and issues two 32x32x16 MFMAs (queries 0-31 and 32-63 against the
+// same 32 corpus rows).  C layout: column = lane&31 = query, rows in the 16 accumulators, so the
+// per-query threshold is one VGPR per lane and the common case costs 32 v_max + 2 compares a tile.
+template <int KSTEPS, int MODE, int WAVES, int RING>
+__global__ __launch_bounds__(WAVES * 64) void k_scan(
+    const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
+    const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, float *__restrict__ gmax,
+    u32x4 *__restrict__ wave_lists, int wave_cap, unsigned int *__restrict__ qcount,
+    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
+{
+    static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
+    __shared__ u32x4 qs[2 * KSTEPS * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+
+    for (int i = tid; i < 2 * KSTEPS * 64; i += WAVES * 64) qs[i] = qfrag[i];
+    float t0 = 0.f, t1 = 0.f;
+    if (MODE == 1) {
+        t0 = tau[lane & 31];
+        t1 = tau[32 + (lane & 31)];
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    const int gw = blockIdx.x * WAVES + wave;
+    u32x4 *mylist = wave_lists + (size_t)gw * wave_cap;
+    unsigned int wcnt = 0;
+
+    int i = gw;
+    const u32x4 *xp = xt + (size_t)(i < nitems ? (int64_t)i * tile_stride : 0) * (KSTEPS * 64) + lane;
+    u32x4 ring[RING];
+    if (i < nitems) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) ring[d] = __builtin_nontemporal_load(xp + d * 64);
+    }
+    while (i < nitems) {
+        const int inext = i + total;
+        const int64_t tile = (int64_t)i * tile_stride;
+        const u32x4 *xn = (inext < nitems) ? xt + (size_t)((int64_t)inext * tile_stride) * (KSTEPS * 64) + lane : xp;
+        const uint32_t vmask = rowmask[tile];  // wave-uniform -> scalar load
+        // the query image is loop-invariant: without this the compiler hoists all 96 LDS pieces (384 VGPRs)
+        // out of the tile loop and spills; the clobber makes it re-read qs per tile, as intended
+        asm volatile("" ::: "memory");
+
+        f32x16 a0 = {0}, a1 = {0};
+        u32x4 b0 = qs[lane], b1 = qs[KSTEPS * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            // order pinned by the sched_barrier: next step's query pieces (LDS), this step's two MFMAs, then the
+            // load that refills this ring slot RING steps ahead (it may belong to the wave's next tile).
+            const int s1 = (s + 1 < KSTEPS) ? s + 1 : s;
+            const u32x4 nb0 = qs[s1 * 64 + lane];
+            const u32x4 nb1 = qs[(KSTEPS + s1) * 64 + lane];
+            const bf16x8 xa = __builtin_bit_cast(bf16x8, ring[s % RING]);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+            const int sp = s + RING;
+            ring[s % RING] = (sp < KSTEPS) ? __builtin_nontemporal_load(xp + sp * 64)
+                                           : __builtin_nontemporal_load(xn + (sp - KSTEPS) * 64);
+            b0 = nb0;
+            b1 = nb1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        if (MODE == 0) {
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = (vmask >> row) & 1u;
+                m0 = fmaxf(m0, ok ? a0[r] : -INFINITY);
+                m1 = fmaxf(m1, ok ? a1[r] : -INFINITY);
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            if (h == 0) {
+                gmax[(size_t)i * 64 + lane] = m0;
+                gmax[(size_t)i * 64 + 32 + lane] = m1;
+            }
+        } else {
+            float m0 = a0[0], m1 = a1[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                m0 = fmaxf(m0, a0[r]);
+                m1 = fmaxf(m1, a1[r]);
+            }
+            const bool any = (m0 >= t0) || (m1 >= t1);
+            if (__ballot(any) != 0ull && vmask != 0u) {
+                const uint32_t rowbase = (uint32_t)(tile * 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const float tq = qb ? t1 : t0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float sc = qb ? a1[r] : a0[r];
+                        const bool pass = ((vmask >> row) & 1u) && (sc >= tq);
+                        const unsigned long long pm = __ballot(pass);
+                        if (pm != 0ull) {
+                            const unsigned int pre = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                            const unsigned int pos = wcnt + pre;
+                            if (pass && pos < (unsigned int)wave_cap) {
+                                u32x4 e;
+                                e.x = f32_bits(sc);
+                                e.y = rowbase + row;
+                                e.z = (uint32_t)(qb * 32 + (lane & 31));
+                                e.w = 0u;
+                                mylist[pos] = e;
+                            }
+                            wcnt += (unsigned int)__popcll(pm);
+                        }
+                    }
+                }
+            }
+        }
+        xp = xn;
+        i = inext;
+    }
+
+    if (MODE == 1) {
+        // Hand the workgroup's candidates over to the per-query lists: count per query in LDS, reserve
+        // one contiguous range per (workgroup, query) with 64 global atomics, scatter.
+        __syncthreads();  // every wave is done with qs (and its list stores have completed)
+        unsigned int *wc = reinterpret_cast<unsigned int *>(qs);  // [WAVES] counts, [64] hist, [64] base, [64] off
+        unsigned int *hist = wc + WAVES;
+        unsigned int *base = hist + 64;
+        unsigned int *off = base + 64;
+        if (lane == 0) {
+            wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+            atomicMax(&status->max_wave_cnt, wcnt);
+            if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
+        }
+        if (tid < 64) {
+            hist[tid] = 0u;
+            off[tid] = 0u;
+        }
+        __syncthreads();
+        const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
+        __syncthreads();
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) {
+                const u32x4 c = wl[(size_t)w * wave_cap + e];
+                const unsigned int q = c.z & 63u;
+                const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+                if (idx < (unsigned int)qcap) {
+                    u32x2 o;
+                    o.x = c.x;
+                    o.y = c.y;
+                    qlist[(size_t)q * qcap + idx] = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ workgroup-wide selection helpers
+
+// k-th largest (1-based) of n keys fetched by get(i), by MSB-first 8-bit radix passes.
+// All threads of the block call it; returns the key to every thread.  Requires 1 <= k <= n.
+template <typename KeyT, int NT, typename Get>
+__device__ KeyT wg_kth_largest(Get get, unsigned int n, unsigned int k, unsigned int *hist /*256*/, unsigned int *bcast /*2*/)
+{
+    constexpr int BITS = sizeof(KeyT) * 8;
+    const int tid = threadIdx.x;
+    KeyT prefix = 0;
+    unsigned int kk = k;
+    for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (unsigned int i = tid; i < n; i += NT) {
+            const KeyT key = get(i);
+            const bool match = (shift == BITS - 8) ? true : ((key >> (shift + 8)) == prefix);
+            if (match) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane t owns bins 255-4t .. 252-4t (descending); suffix-scan across lanes
+            const int b0 = 255 - 4 * tid;
+            const unsigned int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+            const unsigned int mine = c0 + c1 + c2 + c3;
+            unsigned int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = __shfl_up(incl, d);
+                if (tid >= d) incl += o;
+            }
+            const unsigned int excl = incl - mine;
+            if (excl < kk && kk <= incl) {
+                unsigned int rem = kk - excl;
+                int digit;
+                if (rem <= c0) {
+                    digit = b0;
+                } else if (rem <= c0 + c1) {
+                    digit = b0 - 1;
+                    rem -= c0;
+                } else if (rem <= c0 + c1 + c2) {
+                    digit = b0 - 2;
+                    rem -= c0 + c1;
+                } else {
+                    digit = b0 - 3;
+                    rem -= c0 + c1 + c2;
+                }
+                bcast[0] = (unsigned int)digit;
+                bcast[1] = rem;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (KeyT)bcast[0];
+        kk = bcast[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// descending bitonic sort of P (power of two, <= 2*NT) u64 keys in LDS
+template <int NT>
+__device__ void wg_bitonic_desc(unsigned long long *keys, int P)
+{
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (P >> 1); t += NT) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ threshold from the seed sample
+
+// tau[q] = (k-th largest of the G sampled tile maxima of query q) - margin; -inf if G < k or fewer than k
+// sampled tiles hold a valid row.  Any k tiles each contribute >= 1 row at or above their maximum, so
+// at least k valid rows score >= the k-th largest maximum: it is a lower bound of the true k-th score.
+__global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int G, int k, float margin,
+                                             float *__restrict__ tau)
+{
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int bcast[2];
+    const int q = blockIdx.x;
+    float t = -INFINITY;
+    if (G >= k) {
+        const uint32_t key = wg_kth_largest<uint32_t, 256>(
+            [&](unsigned int i) { return ord_f32(gmax[(size_t)i * 64 + q]); }, (unsigned int)G, (unsigned int)k, hist, bcast);
+        t = unord_f32(key);
+        if (t > -INFINITY) t = t - margin;
+    }
+    if (threadIdx.x == 0) tau[q] = t;
+}
+
+// ------------------------------------------------------------------ canonical scoring
+
+// Sequential f32 dot of the canonical query (LDS) with one stored row: acc = acc + q_i*x_i, i ascending,
+// product and sum rounded separately (file is compiled with -ffp-contract=off).  oracle: orc_dot().
+__device__ __forceinline__ float canonical_dot_tiled(const u32x4 *__restrict__ xt, int ksteps, uint32_t row,
+                                                     const float *qv)
+{
+    const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31);
+    float acc = 0.0f;
+    for (int s = 0; s < ksteps; ++s) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const u32x4 pk = xt[base + (size_t)s * 64 + hh * 32];
+            const float *qq = qv + s * 16 + hh * 8;
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float p0 = qq[2 * j] * bf16_bits_f32(w[j] & 0xffffu);
+                acc = acc + p0;
+                float p1 = qq[2 * j + 1] * bf16_bits_f32(w[j] >> 16);
+                acc = acc + p1;
+            }
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf32, int dim, uint32_t row, const float *qv)
+{
+    const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
+    float acc = 0.0f;
+    for (int c = 0; c < (dim >> 2); ++c) {
+        const float4 x = xr[c];
+        float p;
+        p = qv[4 * c] * x.x;
+        acc = acc + p;
+        p = qv[4 * c + 1] * x.y;
+        acc = acc + p;
+        p = qv[4 * c + 2] * x.z;
+        acc = acc + p;
+        p = qv[4 * c + 3] * x.w;
+        acc = acc + p;
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------ final selection
+
+// One workgroup per query.  From the query's candidate list (approximate MFMA scores):
+//   1. a_k   = k-th largest approximate score;
+//   2. keep every candidate with approx >= a_k - margin  (margin >= 2*max|approx - canonical|, so
+//      the canonical top-k is inside);
+//   3. re-score the survivors canonically, key = (ord(score) << 32) | ~row;
+//   4. exact top-k of the keys (descending score, ascending row), written with row_base added.
+template <bool F32>
+__global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist, const unsigned int *__restrict__ qcount,
+                                                  int qcap, unsigned long long *__restrict__ skeys,
+                                                  const float *__restrict__ qn, const u32x4 *__restrict__ xt,
+                                                  const float *__restrict__ xf32, int dim, int ksteps, int k,
+                                                  float margin, int64_t row_base, float *__restrict__ out_scores,
+                                                  int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
+{
+    constexpr int NT = 1024;
+    __shared__ float qv[2048];
+    __shared__ unsigned long long sortbuf[CRH_MAX_K];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int bcast[2];
+    __shared__ unsigned int scount;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned int mtrue = qcount[q];
+    const unsigned int M = mtrue < (unsigned int)qcap ? mtrue : (unsigned int)qcap;
+    if (tid == 0) {
+        atomicMax(&status->max_qcount, mtrue);
+        atomicAdd(&status->candidates, (unsigned long long)mtrue);
+        if (mtrue > (unsigned int)qcap) atomicAdd(&status->q_overflow, 1u);
+        scount = 0u;
+    }
+    for (int i = tid; i < dim; i += NT) qv[i] = qn[(size_t)q * dim + i];
+    float *os = out_scores + (size_t)q * k;
+    int64_t *orow = out_rows + (size_t)q * k;
+    if (M == 0u) {
+        for (int i = tid; i < k; i += NT) {
+            os[i] = -INFINITY;
+            orow[i] = -1;
+        }
+        return;
+    }
+    const u32x2 *ql = qlist + (size_t)q * qcap;
+    unsigned long long *sk = skeys + (size_t)q * qcap;
+    __syncthreads();
+
+    const unsigned int kk = (unsigned int)k < M ? (unsigned int)k : M;
+    const uint32_t akey = wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return ord_f32(bits_f32(ql[i].x)); }, M, kk, hist, bcast);
+    const float lower = unord_f32(akey) - margin;
+
+    for (unsigned int i = tid; i < M; i += NT) {
+        const u32x2 e = ql[i];
+        if (bits_f32(e.x) >= lower) {
+            const unsigned int p = atomicAdd(&scount, 1u);
+            sk[p] = (unsigned long long)e.y;
+        }
+    }
+    __syncthreads();
+    const unsigned int Ms = scount;
+    for (unsigned int p = tid; p < Ms; p += NT) {
+        const uint32_t row = (uint32_t)sk[p];
+        const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv);
+        sk[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+    }
+    __syncthreads();
+
+    const unsigned int k2 = (unsigned int)k < Ms ? (unsigned int)k : Ms;
+    const unsigned long long kkey =
+        wg_kth_largest<unsigned long long, NT>([&](unsigned int i) { return sk[i]; }, Ms, k2, hist, bcast);
+    int P = 1;
+    while (P < (int)k2) P <<= 1;
+    for (int i = tid; i < P; i += NT) sortbuf[i] = 0ull;
+    if (tid == 0) scount = 0u;
+    __syncthreads();
+    for (unsigned int p = tid; p < Ms; p += NT) {
+        const unsigned long long key = sk[p];
+        if (key >= kkey) {
+            const unsigned int o = atomicAdd(&scount, 1u);
+            if (o < (unsigned int)CRH_MAX_K) sortbuf[o] = key;
+        }
+    }
+    wg_bitonic_desc<NT>(sortbuf, P);
+    for (int i = tid; i < k; i += NT) {
+        if (i < (int)k2) {
+            const unsigned long long key = sortbuf[i];
+            os[i] = unord_f32((uint32_t)(key >> 32));
+            orow[i] = row_base + (int64_t)(uint32_t)(~(uint32_t)key);
+        } else {
+            os[i] = -INFINITY;
+            orow[i] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cross-shard merge
+
+// One workgroup per query: nlists*k (score,row) pairs -> top-k by (score desc, row asc).
+// Pairs with row < 0 are padding.  total = nlists*k <= 8192.
+__global__ __launch_bounds__(1024) void k_merge_topk(int nlists, int nq, int k, const float *__restrict__ scores,
+                                                      const int64_t *__restrict__ rows, float *__restrict__ out_scores,
+                                                      int64_t *__restrict__ out_rows)
+{
+    constexpr int NT = 1024;
+    extern __shared__ unsigned char smem_raw[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int total = nlists * k;
+    int P = 1;
+    while (P < total) P <<= 1;
+    float *ss = reinterpret_cast<float *>(smem_raw);
+    int64_t *rr = reinterpret_cast<int64_t *>(smem_raw + (size_t)P * sizeof(float) + ((P & 1) ? 4 : 0));
+    for (int i = tid; i < P; i += NT) {
+        if (i < total) {
+            const int l = i / k, j = i % k;
+            const int64_t r = rows[((size_t)l * nq + q) * k + j];
+            ss[i] = r < 0 ? -INFINITY : scores[((size_t)l * nq + q) * k + j];
+            rr[i] = r < 0 ? INT64_MAX : r;
+        } else {
+            ss[i] = -INFINITY;
+            rr[i] = INT64_MAX;
+        }
+    }
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (P >> 1); t += NT) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const float sa = ss[lo], sb = ss[hi];
+                const int64_t ra = rr[lo], rb = rr[hi];
+                // a ranks before b: higher score, then lower row
+                const bool a_first = (sa > sb) || (sa == sb && ra < rb);
+                if (a_first != desc && !(sa == sb && ra == rb)) {
+                    ss[lo] = sb;
+                    ss[hi] = sa;
+                    rr[lo] = rb;
+                    rr[hi] = ra;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < k; i += NT) {
+        const bool pad = rr[i] == INT64_MAX;
+        out_scores[(size_t)q * k + i] = pad ? -INFINITY : ss[i];
+        out_rows[(size_t)q * k + i] = pad ? -1 : rr[i];
+    }
+}
+
+}  // namespace crh

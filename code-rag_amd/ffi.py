@@ -1,0 +1,256 @@
+"""ctypes binding of ``libcoderag_hip.so`` (declared in ``include/coderag_hip.h``).
+
+This is the only module that touches the native library.  There is no fallback:
+if the shared object is missing or a call fails, a :class:`NativeError` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("CODERAG_HIP_LIB", PKG_DIR / "lib" / "libcoderag_hip.so"))
+
+OK, E_INVALID, E_HIP, E_CAPACITY, E_NODEVICE, E_INTERNAL = 0, -1, -2, -3, -4, -5
+DTYPE_F32, DTYPE_BF16 = 0, 1
+MAX_FILTERS, MAX_K = 8, 1024
+
+# every symbol include/coderag_hip.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "crh_abi_version", "crh_last_error", "crh_device_count", "crh_device_info",
+    "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_tombstone",
+    "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
+    "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
+    "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
+    "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
+    "crh_masked_mean_pool",
+)
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libcoderag_hip error {code}: {message}")
+        self.code = code
+
+
+class Filter(C.Structure):
+    _fields_ = [("col", C.c_int32), ("code", C.c_int32)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("tiles", C.c_int64), ("seed_tiles", C.c_int64),
+                ("candidates", C.c_int64), ("max_query_cands", C.c_int64),
+                ("fallback_used", C.c_int32), ("batches", C.c_int32)]
+
+    def as_dict(self) -> dict:
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the native library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NativeError(E_INTERNAL, f"{LIB_PATH} is missing -- build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
+    L.crh_abi_version.restype = i32
+    L.crh_last_error.restype = C.c_char_p
+    L.crh_device_count.argtypes = [C.POINTER(i32)]
+    L.crh_device_info.argtypes = [i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32)]
+    L.crh_index_create.argtypes = [i32, i32, i64, i32, i32, C.POINTER(vp)]
+    L.crh_index_destroy.argtypes = [vp]
+    L.crh_index_append.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
+    L.crh_index_tombstone.argtypes = [vp, i64, vp]
+    L.crh_index_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.crh_index_clear.argtypes = [vp]
+    L.crh_index_reserve.argtypes = [vp, i64]
+    L.crh_index_read_rows.argtypes = [vp, i64, i64, vp]
+    L.crh_search.argtypes = [vp, i32, vp, i32, i32, C.POINTER(Filter), i32, i64, vp, vp, i32, vp]
+    L.crh_search_finish.argtypes = [vp, vp]
+    L.crh_search_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
+    L.crh_index_set_tuning.argtypes = [vp, i32, i32, i32, i32]
+    L.crh_index_set_profiling.argtypes = [vp, i32]
+    L.crh_index_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.crh_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+    L.crh_index_match_rows.argtypes = [vp, C.POINTER(Filter), i32, i64, vp, C.POINTER(i64)]
+    L.crh_gemm_bf16_bias.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.crh_gemm_bf16_bias_res_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, vp]
+    L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
+    L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    for name in EXPORTS:
+        if name != "crh_last_error":
+            getattr(L, name).restype = i32
+    if L.crh_abi_version() != 1:
+        raise NativeError(E_INTERNAL, "ABI version mismatch between ffi.py and libcoderag_hip.so")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise NativeError(rc, (lib().crh_last_error() or b"").decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().crh_device_count(C.byref(n))
+    return int(n.value) if rc == OK else 0
+
+
+def device_info(device: int = 0) -> dict:
+    name, arch = C.create_string_buffer(256), C.create_string_buffer(256)
+    hbm, cus = C.c_int64(0), C.c_int(0)
+    check(lib().crh_device_info(device, name, 256, arch, 256, C.byref(hbm), C.byref(cus)))
+    return {"name": name.value.decode(), "arch": arch.value.decode(), "hbm_bytes": int(hbm.value),
+            "cu_count": int(cus.value)}
+
+
+def _filters(filters) -> tuple:
+    filters = list(filters or [])
+    if len(filters) > MAX_FILTERS:
+        raise NativeError(E_INVALID, f"at most {MAX_FILTERS} filters are supported")
+    arr = (Filter * max(1, len(filters)))()
+    for i, (col, code) in enumerate(filters):
+        arr[i].col, arr[i].code = int(col), int(code)
+    return arr, len(filters)
+
+
+def _ptr(x) -> int:
+    """Raw address of a numpy array / torch tensor / int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x.data_ptr())  # torch tensor
+
+
+def _is_dev(x) -> int:
+    return int(not isinstance(x, np.ndarray) and getattr(x, "is_cuda", False))
+
+
+class Index:
+    """Owning wrapper of one ``crh_index`` handle (one collection shard on one GPU)."""
+
+    def __init__(self, dim: int = 768, dtype: int = DTYPE_F32, capacity_rows: int = 65536,
+                 n_code_cols: int = 0, device: int = 0):
+        self.dim, self.dtype, self.n_code_cols, self.device = dim, dtype, n_code_cols, device
+        h = C.c_void_p()
+        check(lib().crh_index_create(dim, dtype, capacity_rows, n_code_cols, device, C.byref(h)))
+        self._h = h
+        self.capacity_rows = (capacity_rows + 31) // 32 * 32
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().crh_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _handle(self):
+        if not self._h:
+            raise NativeError(E_INVALID, "index handle is closed")
+        return self._h
+
+    def reserve(self, capacity_rows: int) -> None:
+        check(lib().crh_index_reserve(self._handle(), capacity_rows))
+        self.capacity_rows = max(self.capacity_rows, (capacity_rows + 31) // 32 * 32)
+
+    def append(self, vecs, codes=None, stream: int = 0) -> int:
+        """vecs: float32 [n, dim] numpy array (host) or CUDA torch tensor.  Returns the first new row."""
+        if isinstance(vecs, np.ndarray):
+            vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+            if codes is not None:
+                codes = np.ascontiguousarray(codes, dtype=np.int32)
+        n = int(vecs.shape[0])
+        if n and int(vecs.shape[1]) != self.dim:
+            raise NativeError(E_INVALID, f"vector dim {vecs.shape[1]} != index dim {self.dim}")
+        if codes is not None and tuple(codes.shape) != (n, self.n_code_cols):
+            raise NativeError(E_INVALID, f"codes shape {tuple(codes.shape)} != ({n}, {self.n_code_cols})")
+        if codes is not None and _is_dev(codes) != _is_dev(vecs):
+            raise NativeError(E_INVALID, "vecs and codes must live in the same memory space")
+        first = C.c_int64(-1)
+        check(lib().crh_index_append(self._handle(), n, _ptr(vecs), _is_dev(vecs), _ptr(codes), C.byref(first), stream))
+        return int(first.value)
+
+    def tombstone(self, rows) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(lib().crh_index_tombstone(self._handle(), rows.shape[0], rows.ctypes.data))
+
+    def count(self) -> tuple[int, int]:
+        r, a = C.c_int64(0), C.c_int64(0)
+        check(lib().crh_index_count(self._handle(), C.byref(r), C.byref(a)))
+        return int(r.value), int(a.value)
+
+    def clear(self) -> None:
+        check(lib().crh_index_clear(self._handle()))
+
+    def read_rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), dtype=np.float32)
+        check(lib().crh_index_read_rows(self._handle(), first, n, out.ctypes.data))
+        return out
+
+    def set_tuning(self, seed_tiles: int = 0, wave_cand_cap: int = 0, query_cand_cap: int = 0,
+                   force_fallback: int = -1) -> None:
+        check(lib().crh_index_set_tuning(self._handle(), seed_tiles, wave_cand_cap, query_cand_cap, force_fallback))
+
+    def search(self, queries, k: int, filters=None, row_base: int = 0, out_scores=None, out_rows=None,
+               stream: int = 0):
+        """queries: [nq, dim] float32 numpy (host) or CUDA tensor.  With ``out_*`` CUDA tensors the call is
+        asynchronous (finish with :meth:`search_finish`); otherwise numpy results are returned."""
+        if isinstance(queries, np.ndarray):
+            queries = np.ascontiguousarray(queries, dtype=np.float32)
+            if queries.ndim == 1:
+                queries = queries[None, :]
+        nq = int(queries.shape[0])
+        if nq and int(queries.shape[1]) != self.dim:
+            raise NativeError(E_INVALID, f"query dim {queries.shape[1]} != index dim {self.dim}")
+        farr, nf = _filters(filters)
+        if out_scores is None:
+            out_scores = np.empty((nq, k), dtype=np.float32)
+            out_rows = np.empty((nq, k), dtype=np.int64)
+        check(lib().crh_search(self._handle(), nq, _ptr(queries), _is_dev(queries), k, farr, nf, row_base,
+                               _ptr(out_scores), _ptr(out_rows), _is_dev(out_scores), stream))
+        return out_scores, out_rows
+
+    def search_finish(self, stream: int = 0) -> None:
+        check(lib().crh_search_finish(self._handle(), stream))
+
+    def stats(self) -> dict:
+        s = SearchStats()
+        check(lib().crh_search_get_stats(self._handle(), C.byref(s)))
+        return s.as_dict()
+
+    def set_profiling(self, enable: bool) -> None:
+        check(lib().crh_index_set_profiling(self._handle(), int(enable)))
+
+    def profile(self) -> tuple[float, int]:
+        """(total ms, launches) of the scan kernel since profiling was enabled (HIP events on its stream)."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        check(lib().crh_index_get_profile(self._handle(), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def match_rows(self, filters=None, limit: int = 1) -> np.ndarray:
+        farr, nf = _filters(filters)
+        out = np.empty((max(limit, 1),), dtype=np.int64)
+        n = C.c_int64(0)
+        check(lib().crh_index_match_rows(self._handle(), farr, nf, limit, out.ctypes.data, C.byref(n)))
+        return out[: int(n.value)].copy()
+
+
+def merge_topk(scores, rows, out_scores, out_rows, stream: int = 0) -> None:
+    """scores/rows: CUDA tensors [nlists, nq, k] (f32 / i64); out_*: [nq, k]."""
+    nl, nq, k = (int(v) for v in scores.shape)
+    check(lib().crh_merge_topk(nl, nq, k, _ptr(scores), _ptr(rows), _ptr(out_scores), _ptr(out_rows), stream))

@@ -1,0 +1,189 @@
+/*
+ * coderag_hip.h -- C ABI of libcoderag_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of this repo.  The reference (iAmLakshya/code-rag, Python
+ * package `lattice`) reaches its vector store through qdrant-client gRPC calls and
+ * its encoder through torch/transformers; it has no FFI of its own.  These entry
+ * points are what a ctypes binding for that path binds instead (INTEGRATION.md shows
+ * the stub).  Each entry cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (CRH_E_*);
+ *    crh_last_error() returns a thread-local message for the last failure;
+ *  - no C++ types, no torch types, no exceptions across this boundary;
+ *  - the caller owns every buffer it passes in; the library copies what it keeps;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *  - a handle is used from one thread at a time (the store holds a lock; the
+ *    provider uses a 1-thread executor like providers/unixcoder_provider.py:260);
+ *  - "dev" pointers are device memory on the handle's device, "host" pointers are
+ *    ordinary process memory; `*_on_device` flags say which one a dual-mode
+ *    argument is.
+ */
+#ifndef CODERAG_HIP_H
+#define CODERAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRH_ABI_VERSION 1
+
+/* status codes */
+#define CRH_OK 0
+#define CRH_E_INVALID (-1)  /* bad argument */
+#define CRH_E_HIP (-2)      /* a HIP runtime call failed */
+#define CRH_E_CAPACITY (-3) /* index full / k too large */
+#define CRH_E_NODEVICE (-4) /* no usable gfx950 device */
+#define CRH_E_INTERNAL (-5)
+
+/* stored precision of the corpus */
+#define CRH_DTYPE_F32 0  /* bf16 scan copy + f32 master copy; ids exact vs f32 oracle */
+#define CRH_DTYPE_BF16 1 /* bf16 only; ids exact vs oracle on the bf16-rounded corpus */
+
+#define CRH_MAX_FILTERS 8
+#define CRH_MAX_K 1024
+
+typedef struct crh_index crh_index; /* opaque */
+
+/* One payload equality predicate: column `col` of the dictionary-coded payload must equal
+ * `code`.  Replaces one models.FieldCondition(key, MatchValue(value)) of
+ * embeddings/client.py:171-176; the string<->code dictionaries stay in host Python. */
+typedef struct crh_filter {
+    int32_t col;
+    int32_t code;
+} crh_filter;
+
+/* Counters of the most recent crh_search* call on a handle (diagnostics / bench). */
+typedef struct crh_search_stats {
+    int64_t rows;            /* rows scanned */
+    int64_t tiles;           /* 32-row tiles scanned */
+    int64_t seed_tiles;      /* tiles in the threshold-seeding sample */
+    int64_t candidates;      /* (score,row) pairs that passed the scan threshold, all queries */
+    int64_t max_query_cands; /* largest per-query candidate count */
+    int32_t fallback_used;   /* 1 if the exact chunked fallback ran */
+    int32_t batches;         /* 64-query batches processed */
+} crh_search_stats;
+
+int crh_abi_version(void);
+const char *crh_last_error(void);
+
+/* Number of HIP devices / name+arch of one ("gfx950..." expected).  */
+int crh_device_count(int *count);
+int crh_device_info(int device, char *name_out, int name_cap, char *arch_out, int arch_cap,
+                    int64_t *hbm_bytes_out, int *cu_count_out);
+
+/* ------------------------------------------------------------------ index ------ */
+
+/* Create an empty HBM-resident cosine index.  Replaces
+ * QdrantManager._create_collection_with_indexes (embeddings/client.py:93-113):
+ * VectorParams(size=dim, distance=COSINE) + `n_code_cols` keyword payload indexes.
+ * dim must be a multiple of 16 and <= 768*2 (768 is the tuned case). */
+int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols, int device,
+                     crh_index **out);
+int crh_index_destroy(crh_index *h);
+
+/* Append n vectors (raw, un-normalised f32 [n, dim]; host or device).  Each is passed
+ * through Qdrant's cosine_preprocess and stored; rows are numbered consecutively from
+ * the current count, the first new row is returned.  codes: [n, n_code_cols] int32
+ * (same memory space as vecs) or NULL when n_code_cols == 0.
+ * Replaces the vector half of QdrantManager.upsert (embeddings/client.py:115-130). */
+int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device,
+                     const int32_t *codes, int64_t *first_row_out, void *stream);
+
+/* Mark rows deleted (they stop matching; space is not reclaimed).  rows: host int64[n].
+ * Replaces the point-removal half of QdrantManager.delete (embeddings/client.py:159-169);
+ * which rows a payload filter selects is resolved by the host-side payload table. */
+int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows);
+
+/* rows appended so far / rows still alive (CollectionInfo.points_count, query/engine.py:299-302). */
+int crh_index_count(crh_index *h, int64_t *rows_out, int64_t *alive_out);
+
+/* Drop every row (QdrantManager.clear_collections, embeddings/client.py:213-222). */
+int crh_index_clear(crh_index *h);
+
+/* Grow the row capacity (no-op if already that large); contents and row numbers are kept.
+ * Qdrant collections grow without bound; the HBM arrays are re-allocated and copied device-side. */
+int crh_index_reserve(crh_index *h, int64_t capacity_rows);
+
+/* Copy stored (preprocessed) vectors back as f32 [n, dim] to host: rows first..first+n.
+ * For dtype BF16 these are the bf16-rounded values.  Test / persistence support. */
+int crh_index_read_rows(crh_index *h, int64_t first, int64_t n, float *out_host);
+
+/* -------------------------------------------------------------- search --------- */
+
+/* Cosine top-k of nq raw f32 queries [nq, dim] (host or device) against the alive rows
+ * that satisfy every filter.  Writes scores [nq, k] f32 and rows [nq, k] int64 (host or
+ * device per out_on_device), descending score, ties by lower row, padded with
+ * (-inf, -1) when fewer than k rows qualify.  `row_base` is added to every returned
+ * row (shard offset of a row-sharded corpus).
+ * Replaces QdrantManager.search -> client.query_points (embeddings/client.py:132-157),
+ * batched: the reference issues one query per RPC.
+ * With host outputs the call returns after the results have landed.  With device
+ * outputs it only enqueues on `stream`; call crh_search_finish() before trusting the
+ * buffers (it re-runs the exact fallback if a candidate buffer overflowed). */
+int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device, int k,
+               const crh_filter *filters, int n_filters, int64_t row_base, float *out_scores,
+               int64_t *out_rows, int out_on_device, void *stream);
+
+/* Completes every crh_search enqueued with device outputs since the last finish. */
+int crh_search_finish(crh_index *h, void *stream);
+
+int crh_search_get_stats(crh_index *h, crh_search_stats *out);
+
+/* HIP-event timing of the dominant kernel (the corpus scan), recorded on the search stream around
+ * each launch while enabled; totals since the last enable.  Measurement support for bench.py. */
+int crh_index_set_profiling(crh_index *h, int enable);
+int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_launches);
+
+/* Tuning knobs (0 / negative = keep default): seed sample tiles, per-wave candidate
+ * capacity, per-query candidate capacity, force the exact chunked fallback (testing). */
+int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
+                         int force_fallback);
+
+/* Merge nlists sorted per-shard lists ([nlists, nq, k] device f32 / int64, padded with
+ * (-inf,-1)) into [nq, k]: the step after the all-gather of a row-sharded search
+ * (does not exist in the reference). */
+int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev,
+                   float *out_scores_dev, int64_t *out_rows_dev, void *stream);
+
+/* Filter-only fetch: first `limit` alive rows (ascending) matching the filters, host int64 out;
+ * n_out receives how many.  Replaces QdrantManager.search(query_vector=None, ...) as used by
+ * query/context/builder.py:111-119 and the scroll of embeddings/client.py:178-202. */
+int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters, int64_t limit,
+                         int64_t *rows_out_host, int64_t *n_out);
+
+/* ------------------------------------------------------------- encoder --------- */
+/* UniXcoder = RoBERTa-base geometry encoder (providers/unixcoder_provider.py:137-155 and
+ * the HF RobertaModel it wraps).  All pointers are device pointers; activations bf16,
+ * LayerNorm / softmax / accumulation f32.  T = total tokens (sum of padded rows). */
+
+/* y[T, N] = act(x[T, K] @ w[N, K]^T + bias[N]); act: 0 none, 1 erf-GELU.  out bf16. */
+int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
+                       int act, void *stream);
+
+/* y[T, N] = LayerNorm(x @ w^T + bias + residual) * gamma + beta  (post-LN block end). N == 768. */
+int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual,
+                              const float *gamma, const float *beta, float eps, void *y, int T, int N,
+                              int K, void *stream);
+
+/* Bidirectional self-attention with key-padding by per-row length.  qkv [B, L, 3, H, 64] bf16
+ * (as written by the QKV GEMM), out [B, L, H*64] bf16.  lengths int32 [B]. */
+int crh_attn_fwd_varlen(const void *qkv, const int32_t *lengths, void *out, int B, int L, int H,
+                        void *stream);
+
+/* out[b, t, :] = LN(word[ids[b,t]] + pos[pos_id] + type[0]); pos_id = cumsum(ids != pad) * (ids != pad) + pad.
+ * ids int32 [B, L]; tables bf16; out bf16 [B, L, 768].  Also writes lengths[b] = #non-pad tokens. */
+int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const void *type0,
+                 const float *gamma, const float *beta, float eps, int pad_id, void *out,
+                 int32_t *lengths, int B, int L, int D, void *stream);
+
+/* sent[b, :] = sum_{t < len_b} tok[b, t, :] / len_b  (f32 out, no L2 normalisation). */
+int crh_masked_mean_pool(const void *tok, const int32_t *lengths, float *sent, int B, int L, int D,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODERAG_HIP_H */
