@@ -53,6 +53,24 @@ class SearchStats(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """libcoderag_hip.so is not linked against a HIP runtime (code-rag_amd/build.sh): it binds to the one already
+    in the process.  PyTorch ships its own libamdhip64/libhsa-runtime64; loading a second copy beside it breaks
+    device discovery and makes streams / RCCL unshareable, so torch's copy goes in first, globally."""
+    candidates = []
+    try:
+        import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+        candidates.append(Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so")
+    except Exception:  # torch absent: a plain ROCm install is fine for C-ABI-only use
+        pass
+    candidates += [Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "lib" / "libamdhip64.so"]
+    for cand in candidates:
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+            return
+    raise NativeError(E_NODEVICE, "no libamdhip64.so found (neither PyTorch-ROCm nor $ROCM_PATH/lib)")
+
+
 def lib() -> C.CDLL:
     """Load the native library once; raise loudly when it has not been built."""
     global _lib
@@ -61,6 +79,7 @@ def lib() -> C.CDLL:
     if not LIB_PATH.exists():
         raise NativeError(E_INTERNAL, f"{LIB_PATH} is missing -- build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    _preload_hip_runtime()
     L = C.CDLL(str(LIB_PATH))
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     L.crh_abi_version.restype = i32

@@ -1,0 +1,444 @@
+"""HipVectorStore -- the reference's ``QdrantManager`` surface on an HBM-resident HIP index.
+
+Drop-in for ``src/lattice/embeddings/client.py:18-228`` (and the ``VectorStore`` protocol of
+``src/lattice/core/protocols.py:34-53``): same method names, argument meaning, return shapes and
+error behaviour, but the vectors live in this process's GPU instead of a Qdrant server and the
+cosine top-k runs in ``libcoderag_hip.so`` (``crh_search``).  Payload dictionaries, point ids and
+the value<->code dictionaries of the filterable payload keys stay on the host; the device only
+sees int32 codes.
+
+There is no CPU fallback: without the native library or a gfx950 device ``connect()`` raises
+``VectorStoreError``.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import logging
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Any
+
+import numpy as np
+
+from . import ffi
+from .errors import VectorStoreError
+from .settings import get_settings
+
+logger = logging.getLogger(__name__)
+
+
+class CollectionName(str, Enum):
+    """embeddings/client.py:13-15"""
+
+    CODE_CHUNKS = "code_chunks"
+    SUMMARIES = "summaries"
+
+
+# Payload keys that can appear in a filter, per collection.  The first group mirrors the keyword payload
+# indexes the reference creates (client.py:77-89); the rest are keys its callers filter on without an index
+# (entity_name: query/context/builder.py:111-119; project_name on summaries: query/vector_search.py:144-146).
+FILTER_KEYS: dict[str, tuple[str, ...]] = {
+    CollectionName.CODE_CHUNKS.value: ("file_path", "entity_type", "language", "content_hash", "project_name",
+                                       "entity_name"),
+    CollectionName.SUMMARIES.value: ("file_path", "entity_type", "entity_name", "project_name"),
+}
+
+_DTYPES = {"f32": ffi.DTYPE_F32, "fp32": ffi.DTYPE_F32, "float32": ffi.DTYPE_F32, "bf16": ffi.DTYPE_BF16,
+           "bfloat16": ffi.DTYPE_BF16}
+
+
+@dataclass
+class CollectionInfo:
+    """What ``get_collection_info`` hands back; callers read ``points_count`` (query/engine.py:299-302)."""
+
+    name: str
+    points_count: int
+    vectors_count: int
+    indexed_vectors_count: int
+    status: str = "green"
+    config: dict = field(default_factory=dict)
+
+
+def _hashable(v: Any) -> Any:
+    try:
+        hash(v)
+        return v
+    except TypeError:
+        return repr(v)
+
+
+class _Collection:
+    """One collection: a device index + the host-side id/payload tables."""
+
+    def __init__(self, name: str, dim: int, dtype: int, capacity: int, device: int):
+        self.name = name
+        self.keys = FILTER_KEYS.get(name, ())
+        self.index = ffi.Index(dim, dtype, capacity_rows=capacity, n_code_cols=len(self.keys), device=device)
+        self.ids: list[str | None] = []
+        self.payloads: list[dict | None] = []
+        self.row_of_id: dict[str, int] = {}
+        self.codebooks: list[dict[Any, int]] = [dict() for _ in self.keys]   # value -> code (>= 1; 0 = missing/None)
+        self.rows_by_code: list[dict[int, set[int]]] = [dict() for _ in self.keys]
+
+    # -- payload coding
+    def _encode(self, payload: dict) -> list[int]:
+        codes = []
+        for c, key in enumerate(self.keys):
+            v = payload.get(key)
+            if v is None:
+                codes.append(0)
+                continue
+            book = self.codebooks[c]
+            codes.append(book.setdefault(_hashable(v), len(book) + 1))
+        return codes
+
+    def device_filters(self, filters: dict[str, Any] | None) -> list[tuple[int, int]] | None:
+        """dict -> [(column, code)]; None when some value was never stored (nothing can match)."""
+        out = []
+        for key, value in (filters or {}).items():
+            if key not in self.keys:
+                raise ValueError(f"collection {self.name!r} cannot filter on payload key {key!r} "
+                                 f"(filterable: {', '.join(self.keys)})")
+            c = self.keys.index(key)
+            code = 0 if value is None else self.codebooks[c].get(_hashable(value))
+            if code is None:
+                return None
+            out.append((c, code))
+        return out
+
+    def host_rows(self, filters: dict[str, Any]) -> list[int]:
+        """Alive rows matching every equality, ascending (inverted-index intersection on the host)."""
+        sets = []
+        for c, code in self.device_filters(filters) or [(-1, -1)]:
+            if c < 0:
+                return []
+            sets.append(self.rows_by_code[c].get(code, set()))
+        if not sets:
+            return [r for r, p in enumerate(self.payloads) if p is not None]
+        sets.sort(key=len)
+        rows = set(sets[0])
+        for s in sets[1:]:
+            rows &= s
+        return sorted(rows)
+
+    # -- mutation
+    def _forget(self, rows: list[int]) -> None:
+        for r in rows:
+            payload, pid = self.payloads[r], self.ids[r]
+            if payload is None:
+                continue
+            for c, code in enumerate(self._encode(payload)):
+                self.rows_by_code[c].get(code, set()).discard(r)
+            self.payloads[r] = None
+            self.ids[r] = None
+            if pid is not None and self.row_of_id.get(pid) == r:
+                del self.row_of_id[pid]
+
+    def remove_rows(self, rows: list[int]) -> None:
+        rows = [r for r in rows if self.payloads[r] is not None]
+        if rows:
+            self.index.tombstone(np.asarray(rows, dtype=np.int64))
+            self._forget(rows)
+
+    def upsert(self, ids: list[str], vectors, payloads: list[dict]) -> None:
+        n = len(ids)
+        if n == 0:
+            return
+        vecs = np.asarray(vectors, dtype=np.float32)
+        if vecs.ndim != 2 or vecs.shape[0] != n or len(payloads) != n:
+            raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {vecs.shape}, {len(payloads)})")
+        if vecs.shape[1] != self.index.dim:
+            raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.index.dim}")
+        last = {pid: i for i, pid in enumerate(ids)}           # a repeated id inside one call: last one wins
+        keep = sorted(last.values())
+        stale = [self.row_of_id[pid] for pid in last if pid in self.row_of_id]
+        codes = np.asarray([self._encode(payloads[i]) for i in keep], dtype=np.int32).reshape(len(keep), len(self.keys))
+        rows_now, _ = self.index.count()
+        need = rows_now + len(keep)
+        if need > self.index.capacity_rows:
+            self.index.reserve(max(need, 2 * self.index.capacity_rows))
+        first = self.index.append(vecs[keep], codes if self.keys else None)
+        self.remove_rows(stale)
+        for j, i in enumerate(keep):
+            r = first + j
+            self.ids.append(str(ids[i]))
+            self.payloads.append(dict(payloads[i]))
+            self.row_of_id[str(ids[i])] = r
+            for c, code in enumerate(codes[j]):
+                self.rows_by_code[c].setdefault(int(code), set()).add(r)
+
+    def hit(self, row: int, score: float) -> dict[str, Any]:
+        return {"id": self.ids[row], "score": score, "payload": dict(self.payloads[row] or {})}
+
+    def close(self) -> None:
+        self.index.close()
+
+
+class _RawClient:
+    """The slice of ``AsyncQdrantClient`` that callers reach through ``QdrantManager.client``
+    (health check: client.py:66; admin cleanup: projects/cleanup.py:41-61)."""
+
+    def __init__(self, store: "HipVectorStore"):
+        self._store = store
+
+    async def get_collections(self):
+        names = list(self._store._collections)
+        return type("CollectionsResponse", (), {"collections": [type("CollectionDescription", (), {"name": n})() for n in names]})()
+
+    async def get_collection(self, collection_name: str) -> CollectionInfo:
+        return await self._store.get_collection_info(collection_name)
+
+    @staticmethod
+    def _conditions(flt) -> list[tuple[str, str, Any]]:
+        """Duck-typed qdrant Filter(must=[FieldCondition(key, match=MatchValue|MatchText)]) -> (key, kind, value)."""
+        out = []
+        for cond in (getattr(flt, "must", None) or []):
+            m = getattr(cond, "match", None)
+            if hasattr(m, "text"):
+                out.append((cond.key, "text", m.text))
+            else:
+                out.append((cond.key, "value", getattr(m, "value", None)))
+        return out
+
+    def _select(self, collection_name: str, flt) -> list[int]:
+        col = self._store._col(collection_name)
+        conds = self._conditions(flt)
+        rows = []
+        for r, p in enumerate(col.payloads):
+            if p is None:
+                continue
+            ok = True
+            for key, kind, value in conds:
+                have = p.get(key)
+                ok = ok and ((isinstance(have, str) and str(value) in have) if kind == "text" else have == value)
+            if ok:
+                rows.append(r)
+        return rows
+
+    async def count(self, collection_name: str, count_filter=None, exact: bool = True):
+        n = len(await self._store._run(self._select, collection_name, count_filter))
+        return type("CountResult", (), {"count": n})()
+
+    async def delete(self, collection_name: str, points_selector=None):
+        flt = getattr(points_selector, "filter", points_selector)
+
+        def work():
+            col = self._store._col(collection_name)
+            col.remove_rows(self._select(collection_name, flt))
+        await self._store._run(work)
+
+
+class HipVectorStore:
+    """``QdrantManager`` replacement.  Constructor keeps the reference's positional arguments
+    (client.py:19-30: host, port, grpc_port) and ignores them; GPU options are keyword-only."""
+
+    def __init__(self, host: str | None = None, port: int | None = None, grpc_port: int | None = None, *,
+                 device: int | None = None, dim: int | None = None, dtype: str | None = None,
+                 initial_capacity: int | None = None):
+        s = get_settings()
+        self._host, self._port, self._grpc_port = host, port, grpc_port
+        self._device = s.hip_device if device is None else device
+        # quirk Q3: the reference sizes collections from EMBEDDING_DIMENSIONS (default 1536) although UniXcoder
+        # emits 768; here an explicit dim wins, a UniXcoder provider implies 768, else the env value is used.
+        if dim is None:
+            dim = 768 if s.embedding_provider.startswith("unixcoder") else s.embedding_dimensions
+        self._dimensions = dim
+        name = (dtype or s.hip_store_dtype).lower()
+        if name not in _DTYPES:
+            raise VectorStoreError(f"Unknown store dtype {name!r} (use 'f32' or 'bf16')")
+        self._dtype = _DTYPES[name]
+        self._capacity = initial_capacity or s.hip_initial_capacity
+        self._collections: dict[str, _Collection] = {}
+        self._client: _RawClient | None = None
+        self._executor: ThreadPoolExecutor | None = None
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ plumbing
+    async def _run(self, fn, *args):
+        """All native work goes through one worker thread: one handle, one thread at a time."""
+        if self._executor is None:
+            raise VectorStoreError("Client not connected. Call connect() first.")
+        loop = asyncio.get_running_loop()
+
+        def guarded():
+            with self._lock:
+                return fn(*args)
+        return await loop.run_in_executor(self._executor, guarded)
+
+    def _col(self, collection: str) -> _Collection:
+        name = collection.value if isinstance(collection, CollectionName) else collection
+        if name not in self._collections:
+            raise KeyError(f"collection {name!r} does not exist (call create_collections())")
+        return self._collections[name]
+
+    # ------------------------------------------------------------------ lifecycle (client.py:32-70)
+    async def connect(self) -> None:
+        if self._client is not None:
+            return
+        try:
+            ffi.lib()
+            if ffi.device_count() <= self._device:
+                raise ffi.NativeError(ffi.E_NODEVICE, f"HIP device {self._device} is not visible")
+            info = ffi.device_info(self._device)
+            self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="hip-store")
+            self._client = _RawClient(self)
+            logger.info("Connected to HIP vector store on device %d (%s, %s)", self._device, info["name"], info["arch"])
+        except Exception as e:
+            self._client = None
+            raise VectorStoreError("Failed to connect to Qdrant", cause=e)
+
+    async def close(self) -> None:
+        if self._client is None:
+            return
+        try:
+            await self._run(lambda: [c.close() for c in self._collections.values()])
+            logger.info("Closed HIP vector store")
+        except Exception as e:  # same leniency as client.py:52-55
+            logger.warning(f"Error closing HIP vector store: {e}")
+        finally:
+            self._collections = {}
+            self._client = None
+            if self._executor:
+                self._executor.shutdown(wait=True)
+                self._executor = None
+
+    @property
+    def client(self) -> _RawClient:
+        if self._client is None:
+            raise VectorStoreError("Client not connected. Call connect() first.")
+        return self._client
+
+    async def health_check(self) -> bool:
+        try:
+            await self.client.get_collections()
+            await self._run(ffi.device_info, self._device)
+            return True
+        except Exception as e:
+            logger.warning(f"HIP vector store health check failed: {e}")
+            return False
+
+    # ------------------------------------------------------------------ collections (client.py:72-113)
+    async def create_collections(self) -> None:
+        try:
+            _ = self.client
+
+            def work():
+                for name in (CollectionName.CODE_CHUNKS.value, CollectionName.SUMMARIES.value):
+                    if name not in self._collections:
+                        self._collections[name] = _Collection(name, self._dimensions, self._dtype, self._capacity, self._device)
+                        logger.info(f"Created collection: {name}")
+            await self._run(work)
+        except Exception as e:
+            raise VectorStoreError("Failed to create collections", cause=e)
+
+    async def clear_collections(self) -> None:
+        def drop():
+            for name in (CollectionName.CODE_CHUNKS.value, CollectionName.SUMMARIES.value):
+                col = self._collections.pop(name, None)
+                if col is not None:
+                    col.close()
+        _ = self.client
+        await self._run(drop)
+        await self.create_collections()
+
+    async def get_collection_info(self, collection: str) -> CollectionInfo:
+        try:
+            def work():
+                col = self._col(collection)
+                rows, alive = col.index.count()
+                return CollectionInfo(name=col.name, points_count=alive, vectors_count=alive, indexed_vectors_count=alive,
+                                      config={"size": col.index.dim, "distance": "Cosine", "rows_appended": rows,
+                                              "capacity_rows": col.index.capacity_rows,
+                                              "dtype": "bf16" if col.index.dtype == ffi.DTYPE_BF16 else "f32"})
+            return await self._run(work)
+        except Exception as e:
+            raise VectorStoreError(f"Failed to get collection info for {collection}", cause=e)
+
+    # ------------------------------------------------------------------ data path
+    async def upsert(self, collection: str, ids: list[str], vectors: list[list[float]], payloads: list[dict[str, Any]]) -> None:
+        """client.py:115-130.  Same id again replaces the point (Qdrant upsert semantics)."""
+        try:
+            await self._run(lambda: self._col(collection).upsert(list(ids), vectors, list(payloads)))
+            logger.debug(f"Upserted {len(ids)} vectors to {collection}")
+        except Exception as e:
+            raise VectorStoreError(f"Failed to upsert vectors to {collection}", cause=e)
+
+    def _search_sync(self, collection: str, queries: np.ndarray, limit: int, filters: dict[str, Any] | None):
+        col = self._col(collection)
+        dfilt = col.device_filters(filters)
+        nq = queries.shape[0]
+        if dfilt is None or limit <= 0:
+            return col, np.full((nq, max(limit, 0)), -np.inf, np.float32), np.full((nq, max(limit, 0)), -1, np.int64)
+        scores, rows = col.index.search(queries, limit, filters=dfilt)
+        return col, scores, rows
+
+    async def search(self, collection: str, query_vector: list[float] | None, limit: int = 10,
+                     filters: dict[str, Any] | None = None) -> list[dict[str, Any]]:
+        """client.py:132-157: descending cosine, ``[{"id", "score", "payload"}]``.  ``query_vector=None`` is the
+        filter-only fetch the context builder issues (quirk Q7): first ``limit`` matching points, score 0.0."""
+        try:
+            if query_vector is None:
+                def fetch():
+                    col = self._col(collection)
+                    dfilt = col.device_filters(filters)
+                    rows = [] if dfilt is None else col.index.match_rows(dfilt, limit)
+                    return [col.hit(int(r), 0.0) for r in rows]
+                results = await self._run(fetch)
+            else:
+                q = np.asarray(query_vector, dtype=np.float32).reshape(1, -1)
+                col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
+                results = [col.hit(int(r), float(s)) for s, r in zip(scores[0], rows[0]) if r >= 0]
+            logger.debug(f"Found {len(results)} results in {collection}")
+            return results
+        except Exception as e:
+            raise VectorStoreError(f"Failed to search {collection}", cause=e)
+
+    async def search_batch(self, collection: str, query_vectors, limit: int = 10,
+                           filters: dict[str, Any] | None = None) -> list[list[dict[str, Any]]]:
+        """Batched form of :meth:`search` (not in the reference, which sends one query per RPC): one corpus scan
+        serves up to 64 queries."""
+        try:
+            q = np.asarray(query_vectors, dtype=np.float32)
+            col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
+            return [[col.hit(int(r), float(s)) for s, r in zip(srow, rrow) if r >= 0] for srow, rrow in zip(scores, rows)]
+        except Exception as e:
+            raise VectorStoreError(f"Failed to search {collection}", cause=e)
+
+    async def delete(self, collection: str, filters: dict[str, Any]) -> None:
+        """client.py:159-169: delete every point matching the AND of equalities."""
+        try:
+            def work():
+                col = self._col(collection)
+                col.remove_rows(col.host_rows(filters))
+            await self._run(work)
+            logger.debug(f"Deleted vectors from {collection} with filters: {filters}")
+        except Exception as e:
+            raise VectorStoreError(f"Failed to delete from {collection}", cause=e)
+
+    async def file_needs_update(self, collection: str, file_path: str, content_hash: str) -> bool:
+        """client.py:178-202: True on a miss, on a different stored hash, and on ANY error."""
+        try:
+            def work():
+                col = self._col(collection)
+                rows = col.host_rows({"file_path": file_path})
+                if not rows:
+                    return True
+                return (col.payloads[rows[0]] or {}).get("content_hash") != content_hash
+            return bool(await self._run(work))
+        except Exception as e:
+            logger.warning(f"Error checking file update status: {e}")
+            return True
+
+    async def __aenter__(self):
+        await self.connect()
+        return self
+
+    async def __aexit__(self, exc_type, exc_val, exc_tb):
+        await self.close()
+
+
+# the name the reference's call sites import
+QdrantManager = HipVectorStore

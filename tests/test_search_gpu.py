@@ -183,7 +183,11 @@ def test_device_io_async_and_merge(gpu):
     outs_s = torch.empty((2, 64, 100), dtype=torch.float32, device=dev)
     outs_r = torch.empty((2, 64, 100), dtype=torch.int64, device=dev)
     qd = torch.from_numpy(q).to(dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(device=dev)       # a non-default torch stream: the library must share torch's HIP runtime
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
     for sh in range(2):
         idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n // 2)
         idx.append(torch.from_numpy(x[sh * n // 2:(sh + 1) * n // 2]).to(dev), stream=stream)
@@ -206,5 +210,6 @@ def test_device_io_async_and_merge(gpu):
     torch.cuda.synchronize()
     e2s, e2r = orc.merge_topk(os_, or_)
     assert np.array_equal(mr.cpu().numpy(), e2r) and np.array_equal(ms.cpu().numpy(), e2s)
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
     for idx in shards:
         idx.close()
