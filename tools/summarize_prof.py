@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense a tools/gpu_prof.sh output directory (rocprofv3 CSVs) into profiles/<name>.md + .json.
+
+    python tools/summarize_prof.py gpurun_out/prof_r1b profiles/r01_search_10M
+
+FETCH_SIZE is doubled for the scan kernel as MI355X_MICROARCH.md (section HBM) prescribes for wide
+coalesced 16 B/lane streaming reads on gfx950; WRITE_SIZE is taken as is.  Both are KiB in the CSV.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*", "", name).replace("void ", "").strip()
+    return name[-70:]
+
+
+def main(src: str, dst: str) -> None:
+    out = {"source": src, "kernels": {}, "bench_line": None}
+    log = os.path.join(src, "trace.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{\"metric\""):
+                out["bench_line"] = json.loads(line)
+    for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            k = out["kernels"].setdefault(short(r["Name"]), {})
+            k.update(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3,
+                     max_us=float(r["MaxNs"]) / 1e3, pct=float(r["Percentage"]))
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            key = (short(r["Kernel_Name"]), r["Counter_Name"])
+            agg[key].append(float(r["Counter_Value"]))
+            meta[key[0]] = dict(vgpr=int(r["VGPR_Count"]), accum_vgpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
+                                lds_bytes=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), workgroup=int(r["Workgroup_Size"]),
+                                grid=int(r["Grid_Size"]))
+        for (kn, cn), vals in agg.items():
+            k = out["kernels"].setdefault(kn, {})
+            k.setdefault("pmc", {})[cn] = {"mean": sum(vals) / len(vals), "n": len(vals)}
+            k["resources"] = meta[kn]
+    for kn, k in out["kernels"].items():
+        pmc = k.get("pmc", {})
+        if "FETCH_SIZE" in pmc and "k_scan" in kn:
+            k["hbm_read_bytes_corrected"] = pmc["FETCH_SIZE"]["mean"] * 1024 * 2
+        if "WRITE_SIZE" in pmc:
+            k["hbm_write_bytes"] = pmc["WRITE_SIZE"]["mean"] * 1024
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
+    with open(dst + ".md", "w") as md:
+        md.write(f"# rocprofv3 summary ({src})\n\n")
+        if out["bench_line"]:
+            b = out["bench_line"]
+            md.write(f"bench under the profiler: value={b['value']:.1f} {b['unit']}, ms_per_step={b['ms_per_step']:.3f}, "
+                     f"roofline.achieved={b['roofline']['achieved']:.0f} GB/s (kernel_ms {b['roofline']['kernel_ms']:.4f})\n\n")
+        md.write("| kernel | calls | avg us | min us | max us | % | FETCH KiB | WRITE KiB | HBM read B (corrected) |\n|---|---|---|---|---|---|---|---|---|\n")
+        for kn, k in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("pct", 0)):
+            if "calls" not in k:
+                continue
+            pmc = k.get("pmc", {})
+            md.write(f"| `{kn}` | {k['calls']} | {k['avg_us']:.1f} | {k['min_us']:.1f} | {k['max_us']:.1f} | {k['pct']:.2f} | "
+                     f"{pmc.get('FETCH_SIZE', {}).get('mean', float('nan')):.0f} | {pmc.get('WRITE_SIZE', {}).get('mean', float('nan')):.0f} | "
+                     f"{k.get('hbm_read_bytes_corrected', float('nan')):.4g} |\n")
+    print("wrote", dst + ".md")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
