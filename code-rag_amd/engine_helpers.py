@@ -1,0 +1,49 @@
+"""The two behaviours of ``QueryEngine`` that shape what reaches the ranker, restated as free functions
+(``src/lattice/query/engine.py:315-377``).  The engine itself (LLM planning, Memgraph, response writing) is
+out of scope; these helpers let a batch harness feed the ranker exactly what the reference would."""
+
+from __future__ import annotations
+
+import asyncio
+from typing import Any, Awaitable, Callable
+
+from .query_types import QueryIntent, intent_key
+from .settings import get_settings
+
+_SUMMARY_INTENTS = {i.value for i in (QueryIntent.EXPLAIN_IMPLEMENTATION, QueryIntent.EXPLAIN_RELATIONSHIP,
+                                      QueryIntent.EXPLAIN_DATA_FLOW, QueryIntent.EXPLAIN_ARCHITECTURE,
+                                      QueryIntent.SEARCH_FUNCTIONALITY)}
+
+
+async def execute_vector_search(vector_searcher, query: str, plan, limit: int, language: str | None,
+                                project_name: str | None = None) -> list[dict[str, Any]]:
+    """engine.py:315-346: code hits capped at ``max_vector_results``; explanatory/functional intents also get
+    ``limit // 2`` summary hits appended."""
+    cap = get_settings().max_vector_results
+    results = await vector_searcher.search_code(query=query, limit=min(limit, cap), language=language, project_name=project_name)
+    if intent_key(plan.primary_intent) in _SUMMARY_INTENTS:
+        results.extend(await vector_searcher.search_summaries(query=query, limit=limit // 2, project_name=project_name))
+    return results
+
+
+def centrality_candidates(graph_context, vector_results: list[dict[str, Any]]) -> list[str]:
+    """engine.py:353-363: names of <= 5 primary graph entities and of the first 5 vector hits (graph node id, else
+    entity name), de-duplicated, truncated to ``max_centrality_lookups``.  (The reference iterates a ``set``, so
+    which names survive the truncation is hash-order dependent there; insertion order is used here.)"""
+    names: dict[str, None] = {}
+    for node in graph_context.primary_entities[:5]:
+        names[node.qualified_name or node.name] = None
+    for hit in vector_results[:5]:
+        if hit.get("entity_name"):
+            names[hit.get("graph_node_id") or hit.get("entity_name")] = None
+    return list(names)[: get_settings().max_centrality_lookups]
+
+
+async def get_centrality_scores(lookup: Callable[[str], Awaitable[dict[str, int]]], graph_context,
+                                vector_results: list[dict[str, Any]]) -> dict[str, dict[str, int]]:
+    """engine.py:348-377: one degree lookup per candidate, failures dropped."""
+    names = centrality_candidates(graph_context, vector_results)
+    if not names:
+        return {}
+    answers = await asyncio.gather(*(lookup(n) for n in names), return_exceptions=True)
+    return {n: a for n, a in zip(names, answers) if isinstance(a, dict)}

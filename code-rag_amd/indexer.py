@@ -1,0 +1,247 @@
+"""Indexing and the dataclass-flavoured searcher of ``src/lattice/embeddings/indexer.py`` + the chunk payload
+schema of ``src/lattice/embeddings/chunker.py:12-37``.
+
+``VectorIndexer`` keeps the reference's control flow exactly (hash-skip unless forced -> delete by file ->
+chunk -> embed -> uuid4 ids -> one upsert; every failure wrapped in ``IndexingError``): it is duck-typed over
+the store and the embedder, so it runs unchanged on ``HipVectorStore`` + ``HipUniXcoderProvider``.
+"""
+
+from __future__ import annotations
+
+import logging
+import re
+import uuid
+from collections.abc import Callable
+from dataclasses import asdict, dataclass
+from typing import Any
+
+from .errors import IndexingError
+from .store import CollectionName
+
+logger = logging.getLogger(__name__)
+
+CHUNK_NAME_SEPARATOR = "_part"
+
+
+@dataclass
+class CodeChunk:
+    content: str
+    file_path: str
+    entity_type: str
+    entity_name: str
+    language: str
+    start_line: int
+    end_line: int
+    graph_node_id: str | None = None
+    content_hash: str | None = None
+    project_name: str | None = None
+
+    def to_payload(self) -> dict:
+        """Payload stored next to the vector (chunker.py:24-37): every field, ``content`` included."""
+        p = asdict(self)
+        return {k: p[k] for k in ("file_path", "entity_type", "entity_name", "language", "start_line", "end_line",
+                                  "content", "graph_node_id", "content_hash", "project_name")}
+
+
+_WORDISH = re.compile(r"\w+|[^\w\s]")
+
+
+class CodeChunker:
+    """Entity-wise chunking with line-granular splitting and overlap (chunker.py:40-217).
+
+    The reference counts cl100k_base tokens with ``tiktoken``; when that package is importable it is used, so
+    chunk boundaries are identical.  Without it (this image) a word/punctuation count stands in -- a NEXT row
+    of SURVEY.md section 8f, not part of the measured hot path."""
+
+    def __init__(self, max_tokens: int | None = None, overlap_tokens: int | None = None, encoding_name: str = "cl100k_base"):
+        self.max_tokens = max_tokens or 1000
+        self.overlap_tokens = overlap_tokens if overlap_tokens is not None else 200
+        try:
+            import tiktoken
+            self._encode = tiktoken.get_encoding(encoding_name).encode
+        except Exception:
+            self._encode = _WORDISH.findall
+
+    def count_tokens(self, text: str) -> int:
+        return len(self._encode(text))
+
+    def chunk_file(self, parsed_file, project_name: str | None = None) -> list[CodeChunk]:
+        info = parsed_file.file_info
+        file_path, language = str(info.path), getattr(info.language, "value", info.language)
+        common = dict(file_path=file_path, language=language, content_hash=info.content_hash, project_name=project_name)
+        chunks: list[CodeChunk] = []
+        for entity in parsed_file.all_entities:
+            text = "\n".join(part for part in (entity.signature, f'"""{entity.docstring}"""' if entity.docstring else None,
+                                                entity.code) if part)
+            etype = getattr(entity.type, "value", entity.type)
+            if self.count_tokens(text) <= self.max_tokens:
+                chunks.append(CodeChunk(content=text, entity_type=etype, entity_name=entity.qualified_name,
+                                        start_line=entity.start_line, end_line=entity.end_line,
+                                        graph_node_id=entity.qualified_name, **common))
+            else:
+                chunks.extend(self._split(text, etype, entity.qualified_name, entity.start_line, common))
+        if not chunks and parsed_file.content.strip():
+            chunks.extend(self._split(parsed_file.content, "file", info.path.name, 1, common))
+        return chunks
+
+    def _split(self, text: str, entity_type: str, entity_name: str, first_line: int, common: dict) -> list[CodeChunk]:
+        out: list[CodeChunk] = []
+        held: list[str] = []
+        held_tokens = 0
+        start = first_line
+
+        def emit(final: bool) -> None:
+            name = entity_name if (final and not out) else f"{entity_name}{CHUNK_NAME_SEPARATOR}{len(out) + 1}"
+            out.append(CodeChunk(content="\n".join(held), entity_type=entity_type, entity_name=name, start_line=start,
+                                 end_line=start + len(held) - 1, graph_node_id=entity_name, **common))
+
+        for i, line in enumerate(text.split("\n")):
+            cost = self.count_tokens(line + "\n")
+            if held and held_tokens + cost > self.max_tokens:
+                emit(final=False)
+                tail: list[str] = []
+                tail_tokens = 0
+                for prev in reversed(held):          # carry trailing lines worth <= overlap_tokens into the next chunk
+                    c = self.count_tokens(prev + "\n")
+                    if tail_tokens + c > self.overlap_tokens:
+                        break
+                    tail.insert(0, prev)
+                    tail_tokens += c
+                held, held_tokens = tail, tail_tokens
+                start = first_line + i - len(tail)
+            held.append(line)
+            held_tokens += cost
+        if held:
+            emit(final=True)
+        return out
+
+
+@dataclass
+class CodeSearchResult:
+    score: float
+    file_path: str
+    entity_type: str
+    entity_name: str
+    content: str
+    start_line: int
+    end_line: int
+
+
+@dataclass
+class SummarySearchResult:
+    score: float
+    file_path: str
+    entity_type: str
+    entity_name: str
+    summary: str
+
+
+class VectorIndexer:
+    def __init__(self, qdrant, embedder, chunker=None):
+        self.qdrant = qdrant
+        self.embedder = embedder
+        self.chunker = chunker or CodeChunker()
+
+    async def index_file(self, parsed_file, progress_callback: Callable[[int, int], None] | None = None,
+                         force: bool = False, project_name: str | None = None) -> int:
+        """indexer.py:46-94."""
+        try:
+            file_path = str(parsed_file.file_info.path)
+            if not force and not await self._needs_indexing(file_path, parsed_file.file_info.content_hash):
+                logger.debug(f"Skipping unchanged file: {file_path}")
+                return 0
+            await self.qdrant.delete(CollectionName.CODE_CHUNKS.value, {"file_path": file_path})
+            chunks = self.chunker.chunk_file(parsed_file, project_name=project_name)
+            if not chunks:
+                logger.debug(f"No chunks generated for file: {file_path}")
+                return 0
+            vectors = await self.embedder.embed_with_progress([c.content for c in chunks], progress_callback=progress_callback)
+            await self.qdrant.upsert(collection=CollectionName.CODE_CHUNKS.value, ids=[str(uuid.uuid4()) for _ in chunks],
+                                     vectors=vectors, payloads=[c.to_payload() for c in chunks])
+            logger.info(f"Indexed {len(chunks)} chunks from {file_path}")
+            return len(chunks)
+        except Exception as e:
+            raise IndexingError(f"Failed to index file {parsed_file.file_info.path}", stage="file_indexing", cause=e)
+
+    async def index_files(self, parsed_files: list, progress_callback: Callable[[int, int], None] | None = None,
+                          project_name: str | None = None) -> int:
+        """Sequential; a failing file is logged and skipped (indexer.py:96-119)."""
+        total = 0
+        for done, parsed_file in enumerate(parsed_files, start=1):
+            try:
+                total += await self.index_file(parsed_file, project_name=project_name)
+            except IndexingError as e:
+                logger.error(f"Failed to index file: {e}")
+                continue
+            if progress_callback:
+                progress_callback(done, len(parsed_files))
+        logger.info(f"Indexed total of {total} chunks from {len(parsed_files)} files")
+        return total
+
+    async def index_summary(self, file_path: str, entity_type: str, entity_name: str, summary: str,
+                            graph_node_id: str | None = None) -> None:
+        """One embed + one upsert into ``summaries`` (indexer.py:121-152)."""
+        try:
+            vector = await self.embedder.embed(summary)
+            await self.qdrant.upsert(collection=CollectionName.SUMMARIES.value, ids=[str(uuid.uuid4())], vectors=[vector],
+                                     payloads=[{"file_path": file_path, "entity_type": entity_type, "entity_name": entity_name,
+                                                "summary": summary, "graph_node_id": graph_node_id}])
+            logger.info(f"Indexed summary for {entity_name} in {file_path}")
+        except Exception as e:
+            raise IndexingError(f"Failed to index summary for {entity_name}", stage="summary_indexing", cause=e)
+
+    async def _needs_indexing(self, file_path: str, content_hash: str) -> bool:
+        return await self.qdrant.file_needs_update(CollectionName.CODE_CHUNKS.value, file_path, content_hash)
+
+
+def _only_set(**kw: Any) -> dict[str, Any] | None:
+    chosen = {k: v for k, v in kw.items() if v}
+    return chosen or None
+
+
+class VectorSearcher:
+    """Dataclass-returning searcher (indexer.py:162-257); every failure -> ``IndexingError`` (quirk Q5)."""
+
+    def __init__(self, qdrant, embedder):
+        self.qdrant = qdrant
+        self.embedder = embedder
+
+    async def _run(self, collection: str, query: str, limit: int, filters: dict | None, stage: str, what: str):
+        try:
+            vector = await self.embedder.embed(query)
+            return await self.qdrant.search(collection=collection, query_vector=vector, limit=limit, filters=filters)
+        except Exception as e:
+            logger.error(f"{what} search failed: {e}")
+            raise IndexingError(f"Failed to search {what.lower()} for query: {query}", stage=stage, cause=e)
+
+    async def search_code(self, query: str, limit: int = 10, language: str | None = None, entity_type: str | None = None,
+                          project_name: str | None = None) -> list[CodeSearchResult]:
+        hits = await self._run(CollectionName.CODE_CHUNKS.value, query, limit,
+                               _only_set(language=language, entity_type=entity_type, project_name=project_name),
+                               "code_search", "Code")
+        return self._format_code_results(hits)
+
+    async def search_summaries(self, query: str, limit: int = 10, entity_type: str | None = None) -> list[SummarySearchResult]:
+        hits = await self._run(CollectionName.SUMMARIES.value, query, limit, _only_set(entity_type=entity_type),
+                               "summary_search", "Summaries")
+        return self._format_summary_results(hits)
+
+    @staticmethod
+    def _format_code_results(results: list[dict]) -> list[CodeSearchResult]:
+        out = []
+        for hit in results:
+            p = hit["payload"]
+            out.append(CodeSearchResult(score=hit["score"], file_path=p.get("file_path", ""), entity_type=p.get("entity_type", ""),
+                                        entity_name=p.get("entity_name", ""), content=p.get("content", ""),
+                                        start_line=p.get("start_line", 0), end_line=p.get("end_line", 0)))
+        return out
+
+    @staticmethod
+    def _format_summary_results(results: list[dict]) -> list[SummarySearchResult]:
+        out = []
+        for hit in results:
+            p = hit["payload"]
+            out.append(SummarySearchResult(score=hit["score"], file_path=p.get("file_path", ""),
+                                           entity_type=p.get("entity_type", ""), entity_name=p.get("entity_name", ""),
+                                           summary=p.get("summary", "")))
+        return out

@@ -1,0 +1,180 @@
+"""Embedding-provider plugin surface and the HIP UniXcoder provider.
+
+* ``ProviderConfig`` / ``BaseEmbeddingProvider`` restate ``src/lattice/providers/base.py:21-64,138-225``:
+  same constructor, ``embed`` (retried 5x, exponential back-off 1..60 s), ``embed_batch`` (sequential
+  slices under a semaphore), ``set_concurrency`` and the overridable ``_embed_impl``.
+* ``HipUniXcoderProvider`` replaces ``UniXcoderEmbeddingProvider``
+  (``src/lattice/providers/unixcoder_provider.py:218-292``): same constructor and ``embedding_dim``, work
+  offloaded to a 1-thread executor, but the encoder forward runs in hand-written HIP kernels
+  (``encoder.HipUniXcoder``) and ragged batches are padded instead of failing (quirk Q1).
+* ``get_embedding_provider`` restates the factory branch (``src/lattice/providers/factory.py:61-97,202-242``)
+  for the provider names that are on this path.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import logging
+import os
+from abc import ABC, abstractmethod
+from collections.abc import Sequence
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+
+from .errors import ConfigurationError, EmbeddingError
+from .settings import get_settings
+
+logger = logging.getLogger(__name__)
+
+RETRY_MAX_ATTEMPTS = 5
+RETRY_MULTIPLIER = 1
+RETRY_MIN_WAIT = 1
+RETRY_MAX_WAIT = 60
+
+
+class RetryError(Exception):
+    """Raised by ``embed`` after the last attempt failed -- the reference's tenacity decorator (base.py:162-169,
+    ``reraise`` left at its default) surfaces ``tenacity.RetryError`` there, not the original exception."""
+
+    def __init__(self, last_exception: BaseException, attempts: int):
+        super().__init__(f"RetryError after {attempts} attempts: {last_exception!r}")
+        self.last_exception = last_exception
+        self.attempts = attempts
+
+
+def _backoff_seconds(attempt: int) -> float:
+    """tenacity.wait_exponential(multiplier=1, min=1, max=60) after failed attempt number `attempt` (1-based)."""
+    return float(max(RETRY_MIN_WAIT, min(RETRY_MULTIPLIER * 2 ** (attempt - 1), RETRY_MAX_WAIT)))
+
+
+@dataclass
+class ProviderConfig:
+    provider: str
+    model: str
+    api_key: str | None = None
+    base_url: str | None = None
+    temperature: float = 0.7
+    max_tokens: int = 1000
+    extra: dict = field(default_factory=dict)
+
+    @classmethod
+    def from_env_prefix(cls, prefix: str) -> "ProviderConfig":
+        return cls(
+            provider=os.getenv(f"{prefix}_PROVIDER", "openai").lower(),
+            model=os.getenv(f"{prefix}_MODEL", "gpt-4o"),
+            api_key=os.getenv(f"{prefix}_API_KEY") or os.getenv("OPENAI_API_KEY"),
+            base_url=os.getenv(f"{prefix}_BASE_URL"),
+        )
+
+
+class BaseEmbeddingProvider(ABC):
+    # seconds -> awaitable; tests replace it so the back-off does not actually sleep
+    _sleep = staticmethod(asyncio.sleep)
+
+    def __init__(self, config: ProviderConfig):
+        self.config = config
+        self._semaphore = asyncio.Semaphore(5)
+
+    @abstractmethod
+    async def _embed_impl(self, texts: list[str]) -> list[list[float]]:
+        """One vector per text, input order, Python floats."""
+
+    async def embed(self, text: str) -> list[float]:
+        """Every exception is retried, deterministic ones included (as the reference does)."""
+        attempt = 0
+        while True:
+            attempt += 1
+            try:
+                return (await self._embed_batch_internal([text]))[0]
+            except Exception as e:  # noqa: BLE001 - mirrors tenacity's catch-all
+                if attempt >= RETRY_MAX_ATTEMPTS:
+                    raise RetryError(e, attempt) from e
+                await self._sleep(_backoff_seconds(attempt))
+
+    async def _embed_batch_internal(self, texts: list[str]) -> list[list[float]]:
+        async with self._semaphore:
+            return await self._embed_impl(texts)
+
+    async def embed_batch(self, texts: Sequence[str], batch_size: int = 100) -> list[list[float]]:
+        items = list(texts)
+        vectors: list[list[float]] = []
+        for start in range(0, len(items), batch_size):
+            vectors.extend(await self._embed_batch_internal(items[start:start + batch_size]))
+        logger.debug(f"Generated {len(vectors)} embeddings")
+        return vectors
+
+    def set_concurrency(self, max_concurrent: int) -> None:
+        self._semaphore = asyncio.Semaphore(max_concurrent)
+
+
+class HipUniXcoderProvider(BaseEmbeddingProvider):
+    """UniXcoder embeddings from the MI355X HIP encoder.  ``model`` may be a local checkpoint directory
+    (``config.json`` + weights + ``vocab.json``/``merges.txt``); the hub name ``microsoft/unixcoder-base`` cannot be
+    fetched offline, in which case ``CODERAG_HIP_WEIGHTS`` must point at a local copy, or
+    ``extra={"synthetic_weights": seed}`` selects seeded random weights with the hashing tokenizer (benchmarks/tests)."""
+
+    EMBEDDING_DIM = 768
+
+    def __init__(self, config: ProviderConfig | None = None, max_length: int = 512):
+        try:
+            import torch  # noqa: F401
+        except ImportError as e:  # unixcoder_provider.py:245-249
+            raise RuntimeError("UniXcoder requires the 'torch' package (PyTorch-ROCm).") from e
+        if config is None:
+            config = ProviderConfig(provider="unixcoder-hip", model="microsoft/unixcoder-base")
+        super().__init__(config)
+        self.max_length = max_length
+        self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="hip-unixcoder")
+        self._model = None
+        logger.info("Initializing HIP UniXcoder embedding provider...")
+
+    def _load(self):
+        if self._model is None:
+            from .encoder import load_unixcoder
+            self._model = load_unixcoder(self.config.model, extra=self.config.extra)
+        return self._model
+
+    def _embed_sync(self, texts: list[str]) -> list[list[float]]:
+        if not texts:
+            return []
+        try:
+            model = self._load()
+            return model.embed_texts(texts, max_length=self.max_length)
+        except Exception as e:
+            raise EmbeddingError("HIP UniXcoder embedding failed", cause=e)
+
+    async def _embed_impl(self, texts: list[str]) -> list[list[float]]:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self._executor, self._embed_sync, list(texts))
+
+    @property
+    def embedding_dim(self) -> int:
+        return self.EMBEDDING_DIM
+
+    def __del__(self):
+        if hasattr(self, "_executor"):
+            self._executor.shutdown(wait=False)
+
+
+# the class name the reference's factory imports (factory.py:228-230)
+UniXcoderEmbeddingProvider = HipUniXcoderProvider
+
+_REMOTE = {"openai", "ollama", "google"}
+
+
+def get_embedding_provider(provider: str | None = None, model: str | None = None, api_key: str | None = None,
+                           base_url: str | None = None) -> BaseEmbeddingProvider:
+    """Name -> provider.  ``unixcoder`` and ``unixcoder-hip`` both select the HIP encoder; the remote HTTP
+    providers of the reference are outside this repo's scope and are reported as such."""
+    settings = get_settings()
+    name = (provider or settings.embedding_provider).lower()
+    if name in ("unixcoder", "unixcoder-hip"):
+        weights = model or settings.hip_weights or "microsoft/unixcoder-base"
+        return HipUniXcoderProvider(ProviderConfig(provider=name, model=weights, api_key=api_key, base_url=base_url))
+    if name in _REMOTE:
+        raise ConfigurationError(f"Embedding provider '{name}' is a remote HTTP API and is not part of the MI355X hot path; "
+                                 "use 'unixcoder' / 'unixcoder-hip' (or keep the reference's provider for it).")
+    if name == "anthropic":
+        raise ConfigurationError("Anthropic does not provide embedding models. "
+                                 "Use 'openai', 'ollama', 'google', or 'unixcoder' for embeddings.")
+    raise ConfigurationError(f"Unknown embedding provider: {name}. Supported providers: openai, ollama, google, unixcoder")

@@ -131,7 +131,13 @@ def search_fp64(corpus_pre: np.ndarray, queries_pre: np.ndarray, k: int, alive: 
     if alive is not None:
         s[:, ~np.asarray(alive, dtype=bool)] = -np.inf
     order = np.lexsort((np.broadcast_to(np.arange(x.shape[0]), s.shape), -s), axis=1)[:, :k]
-    return np.take_along_axis(s, order, axis=1), order.astype(np.int64)
+    top = np.take_along_axis(s, order, axis=1)
+    rows = np.where(np.isneginf(top), -1, order).astype(np.int64)
+    pad = k - rows.shape[1]
+    if pad > 0:
+        top = np.concatenate([top, np.full((top.shape[0], pad), -np.inf)], axis=1)
+        rows = np.concatenate([rows, np.full((rows.shape[0], pad), -1, np.int64)], axis=1)
+    return top, rows
 
 
 def search_blas(corpus_pre: np.ndarray, queries_pre: np.ndarray, k: int):

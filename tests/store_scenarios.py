@@ -1,0 +1,117 @@
+"""Store behaviour scenarios shared by the CPU tier (FakeIndex) and the GPU tier (real HIP index)."""
+import numpy as np
+
+from coderag_amd.errors import VectorStoreError
+from oracle import search as orc
+
+
+def _payload(i, file, lang="python", etype="function", proj="p1", h="h1"):
+    return {"file_path": file, "entity_type": etype, "entity_name": f"ent{i}", "language": lang, "start_line": i, "end_line": i + 3,
+            "content": f"def ent{i}(): pass", "graph_node_id": f"mod.ent{i}", "content_hash": h, "project_name": proj}
+
+
+async def run_store_scenarios(s):
+    rng = np.random.default_rng(42)
+    n = 200
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    files = [f"/proj/f{i % 10}.py" for i in range(n)]
+    langs = ["python" if i % 3 else "typescript" for i in range(n)]
+    payloads = [_payload(i, files[i], lang=langs[i], etype="class" if i % 7 == 0 else "function", proj="p1" if i < 150 else "p2",
+                         h=f"hash{i % 10}") for i in range(n)]
+    ids = [f"00000000-0000-4000-8000-{i:012d}" for i in range(n)]
+
+    async with s:
+        assert await s.health_check() is True
+        await s.create_collections()
+        await s.create_collections()                                    # idempotent
+        info = await s.get_collection_info("code_chunks")
+        assert info.points_count == 0
+        assert await s.search("code_chunks", vecs[0].tolist(), limit=5) == []
+        await s.upsert("code_chunks", ids[:120], vecs[:120].tolist(), payloads[:120])   # python lists, as the reference passes
+        await s.upsert("code_chunks", ids[120:], vecs[120:].tolist(), payloads[120:])   # crosses the initial capacity of 64
+        assert (await s.get_collection_info("code_chunks")).points_count == n
+
+        q = rng.standard_normal(768).astype(np.float32)
+        es, er = orc.cosine_search(vecs, q[None], 10)
+        hits = await s.search("code_chunks", q.tolist(), limit=10)
+        assert [h["id"] for h in hits] == [ids[r] for r in er[0]]
+        assert [h["score"] for h in hits] == [float(v) for v in es[0]]
+        assert hits[0]["payload"] == payloads[er[0][0]] and set(hits[0]) == {"id", "score", "payload"}
+        assert all(isinstance(h["score"], float) for h in hits)
+
+        # equality filters are AND-ed (client.py:171-176)
+        want = [i for i in range(n) if langs[i] == "typescript" and payloads[i]["project_name"] == "p2"]
+        hits = await s.search("code_chunks", q.tolist(), limit=500, filters={"language": "typescript", "project_name": "p2"})
+        assert sorted(h["id"] for h in hits) == sorted(ids[i] for i in want)
+        assert [h["score"] for h in hits] == sorted((h["score"] for h in hits), reverse=True)
+        assert await s.search("code_chunks", q.tolist(), limit=5, filters={"language": "cobol"}) == []
+        try:
+            await s.search("code_chunks", q.tolist(), filters={"no_such_key": 1})
+            raise AssertionError("unknown filter key must fail")
+        except VectorStoreError as e:
+            assert "Failed to search code_chunks" in str(e)
+
+        # filter-only fetch (query_vector=None; query/context/builder.py:111-119)
+        got = await s.search("code_chunks", None, limit=1, filters={"entity_name": "ent17", "file_path": files[17]})
+        assert len(got) == 1 and got[0]["id"] == ids[17] and got[0]["payload"]["start_line"] == 17
+
+        # batch search = the same answers as single queries
+        qs = rng.standard_normal((5, 768)).astype(np.float32)
+        batch = await s.search_batch("code_chunks", qs, limit=7, filters={"language": "python"})
+        for qi, per_q in zip(qs, batch):
+            single = await s.search("code_chunks", qi.tolist(), limit=7, filters={"language": "python"})
+            assert per_q == single
+
+        # file_needs_update (client.py:178-202)
+        assert await s.file_needs_update("code_chunks", "/proj/f3.py", "hash3") is False
+        assert await s.file_needs_update("code_chunks", "/proj/f3.py", "other") is True
+        assert await s.file_needs_update("code_chunks", "/proj/nope.py", "hash3") is True
+
+        # delete by file, as VectorIndexer.index_file does before re-indexing (indexer.py:61-64)
+        await s.delete("code_chunks", {"file_path": "/proj/f3.py"})
+        assert (await s.get_collection_info("code_chunks")).points_count == n - 20
+        hits = await s.search("code_chunks", q.tolist(), limit=500)
+        assert all(h["payload"]["file_path"] != "/proj/f3.py" for h in hits) and len(hits) == n - 20
+        await s.delete("code_chunks", {"file_path": "/proj/f3.py"})           # nothing left: no-op
+        assert await s.file_needs_update("code_chunks", "/proj/f3.py", "hash3") is True
+
+        # upsert of an existing id replaces the point
+        new_vec = (-vecs[5]).tolist()
+        await s.upsert("code_chunks", [ids[5]], [new_vec], [dict(payloads[5], content="changed")])
+        assert (await s.get_collection_info("code_chunks")).points_count == n - 20
+        top = await s.search("code_chunks", new_vec, limit=1)
+        assert top[0]["id"] == ids[5] and top[0]["payload"]["content"] == "changed" and abs(top[0]["score"] - 1.0) < 1e-5
+
+        # summaries collection + raw client used by admin cleanup (projects/cleanup.py:41-61)
+        await s.upsert("summaries", ["s1", "s2"], vecs[:2].tolist(),
+                       [{"file_path": "/proj/f0.py", "entity_type": "function", "entity_name": "ent0", "summary": "does x", "graph_node_id": None},
+                        {"file_path": "/other/g.py", "entity_type": "class", "entity_name": "G", "summary": "does y", "graph_node_id": "G"}])
+        hits = await s.search("summaries", vecs[1].tolist(), limit=2, filters={"entity_type": "class"})
+        assert [h["id"] for h in hits] == ["s2"]
+        assert await s.search("summaries", vecs[1].tolist(), limit=2, filters={"project_name": "p1"}) == []   # quirk Q6
+        cols = await s.client.get_collections()
+        assert {c.name for c in cols.collections} == {"code_chunks", "summaries"}
+
+        class _M:            # duck-typed qdrant models
+            def __init__(self, **kw):
+                self.__dict__.update(kw)
+        flt = _M(must=[_M(key="file_path", match=_M(text="/proj/"))])
+        assert (await s.client.count("code_chunks", count_filter=flt)).count == n - 20
+        await s.client.delete("code_chunks", points_selector=_M(filter=_M(must=[_M(key="file_path", match=_M(text="f1.py"))])))
+        assert (await s.get_collection_info("code_chunks")).points_count == n - 40
+
+        # bad input is wrapped
+        try:
+            await s.upsert("code_chunks", ["x"], [[0.0] * 10], [{}])
+            raise AssertionError("dimension mismatch must fail")
+        except VectorStoreError as e:
+            assert "Failed to upsert vectors to code_chunks" in str(e)
+
+        await s.clear_collections()
+        assert (await s.get_collection_info("code_chunks")).points_count == 0
+        assert (await s.get_collection_info("summaries")).points_count == 0
+    try:
+        _ = s.client
+        raise AssertionError("closed store must not hand out a client")
+    except VectorStoreError:
+        pass

@@ -1,0 +1,50 @@
+"""HybridRanker restatement against outputs captured from the reference's own ranking code
+(tests/golden/ranking_reference.json, produced by tools/gen_goldens.py)."""
+import dataclasses
+import json
+import os
+
+import pytest
+
+import coderag_amd  # noqa: F401
+from coderag_amd.query_types import ExtractedEntity, GraphContext, GraphNode, QueryIntent, QueryPlan
+from coderag_amd.ranking import HybridRanker, RankingConfig, ranked_results_to_search_results
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_reference.json")))
+ROLES = ("primary_entities", "callers", "callees", "parent_classes", "child_classes", "methods")
+
+
+def build_inputs(s):
+    plan = QueryPlan(original_query=s["name"], primary_intent=QueryIntent(s["intent"]),
+                     entities=[ExtractedEntity(name=e) for e in s["entities"]])
+    ctx = GraphContext(**{role: [GraphNode(**n) for n in s["graph"].get(role, [])] for role in ROLES})
+    return plan, ctx, [dict(v) for v in s["vector"]], s["centrality"]
+
+
+@pytest.mark.parametrize("scenario", GOLD["scenarios"], ids=lambda s: s["name"])
+def test_ranker_matches_reference_output(scenario):
+    plan, ctx, vec, cent = build_inputs(scenario)
+    ranked = HybridRanker().rank_results(plan, ctx, vec, cent)
+    got = json.loads(json.dumps([dataclasses.asdict(r) for r in ranked], default=str))
+    assert got == scenario["expected"]["ranked"]            # every score, order, signal, source -- floats exact
+    flat = json.loads(json.dumps(ranked_results_to_search_results(ranked), default=str))
+    assert flat == scenario["expected"]["flattened"]
+
+
+def test_documented_example_values():
+    s = next(x for x in GOLD["scenarios"] if x["name"] == "survey_example")
+    ranked = HybridRanker().rank_results(*build_inputs(s))
+    assert [r.final_score for r in ranked] == [0.8700000000000001, 0.43000000000000005]
+    assert all(r.source == "vector" for r in ranked)
+    assert set(ranked[0].signal_scores) == {"vector_similarity", "query_entity_match", "centrality", "code_quality"}
+
+
+def test_caps_and_config_override():
+    s = next(x for x in GOLD["scenarios"] if x["name"] == "total_cap")
+    plan, ctx, vec, cent = build_inputs(s)
+    assert len(HybridRanker().rank_results(plan, ctx, vec, cent)) == 50
+    small = HybridRanker(RankingConfig(max_per_file=1, max_total=7)).rank_results(plan, ctx, vec, cent)
+    assert len(small) == 7 and len({r.file_path for r in small}) == 7
+    w = RankingConfig().weights_for(QueryIntent.FIND_IMPLEMENTATIONS)   # intent without a row keeps defaults
+    assert (w["graph_weight"], w["vector_weight"]) == (0.5, 0.5)
+    assert RankingConfig().weights_for("find_call_chain")["graph_weight"] == 0.9   # plain strings work too
