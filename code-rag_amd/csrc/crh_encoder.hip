@@ -1,27 +1,485 @@
-// crh_encoder.hip -- UniXcoder encoder entry points (placeholder bodies until the kernels land).
+// crh_encoder.hip -- UniXcoder (RoBERTa-base geometry) encoder kernels for gfx950 / CDNA4.
+//
+// Replaces the torch/transformers forward behind UniXcoder.forward
+// (src/lattice/providers/unixcoder_provider.py:137-155; HF modeling_roberta.py embeddings :56-121,
+// self-attention :158-183, output+LN :329-340, FFN :372-398).  bf16 activations and weights,
+// f32 accumulation / LayerNorm / softmax / pooling.  Oracle: oracle/encoder.py (pinned against HF).
+//
+// Kernels
+//   k_embed_ln    gather word+type+position rows, LayerNorm, also emits the key-validity bitmask (ids != pad)
+//   k_gemm_nt     C[M,N] = epi(A[M,K] . W[N,K]^T + bias): 128x128x64 tiles, v_mfma_f32_16x16x32_bf16, XOR-swizzled LDS,
+//                 register-prefetched double buffering; epilogues: bias | bias+erf-GELU | bias+residual
+//   k_layernorm   in-place row LayerNorm over 768 (one wave per row)
+//   k_attn        per (batch row, head): K and V of the whole row staged once in LDS, S^T = K.Q^T and O^T = V^T.P^T on
+//                 MFMA with the softmax statistics lane-local (query on the lane), V consumed through
+//                 ds_read_b64_tr_b16 so it is never transposed in memory; keys masked by the validity bitmask
+//   k_pool        masked mean over valid tokens (f32 out, no L2 normalisation)
+#include <cmath>
+
 #include "crh_common.h"
 
+namespace crh {
+namespace enc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(unsigned int b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ unsigned int f2bf(float x)
+{
+    unsigned int u = __builtin_bit_cast(unsigned int, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u | 0x00400000u) >> 16;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ------------------------------------------------------------------ embeddings + LayerNorm
+
+// grid = B, block = 256.  ids int32 [B,L]; out bf16 [B,L,768]; kmask u64 [B][L/64] (bit = ids != pad).
+// position id = cumsum(ids != pad) * (ids != pad) + pad   (modeling_roberta.py create_position_ids_from_input_ids)
+__global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ ids, const bf16_t *__restrict__ word,
+                                                  const bf16_t *__restrict__ pos, const bf16_t *__restrict__ type0,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                  int pad_id, bf16_t *__restrict__ out, unsigned long long *__restrict__ kmask,
+                                                  int L, int D)
+{
+    extern __shared__ int posid[];  // [L]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *row = ids + (size_t)b * L;
+    for (int t0 = wave * 64; t0 < L; t0 += 256) {  // validity bitmask, 64 tokens per wave step
+        const bool v = row[t0 + lane] != pad_id;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) kmask[(size_t)b * (L >> 6) + (t0 >> 6)] = m;
+    }
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < L; ++t) {
+            const bool v = row[t] != pad_id;
+            run += v ? 1 : 0;
+            posid[t] = (v ? run : 0) + pad_id;
+        }
+    }
+    __syncthreads();
+    constexpr int per = 3;  // D == 768: 3 groups of 4 elements per lane
+    for (int t = wave; t < L; t += 4) {
+        const bf16_t *w = word + (size_t)row[t] * D;
+        const bf16_t *p = pos + (size_t)posid[t] * D;
+        float x[12];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int e = i * 256 + lane * 4;
+            const u32x2 wv = *reinterpret_cast<const u32x2 *>(w + e);
+            const u32x2 pv = *reinterpret_cast<const u32x2 *>(p + e);
+            const u32x2 tv = *reinterpret_cast<const u32x2 *>(type0 + e);
+            x[4 * i + 0] = (bf2f(wv.x & 0xffffu) + bf2f(tv.x & 0xffffu)) + bf2f(pv.x & 0xffffu);
+            x[4 * i + 1] = (bf2f(wv.x >> 16) + bf2f(tv.x >> 16)) + bf2f(pv.x >> 16);
+            x[4 * i + 2] = (bf2f(wv.y & 0xffffu) + bf2f(tv.y & 0xffffu)) + bf2f(pv.y & 0xffffu);
+            x[4 * i + 3] = (bf2f(wv.y >> 16) + bf2f(tv.y >> 16)) + bf2f(pv.y >> 16);
+            s += x[4 * i] + x[4 * i + 1] + x[4 * i + 2] + x[4 * i + 3];
+        }
+        const float mu = wave_sum(s) / D;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * per; ++i) v += (x[i] - mu) * (x[i] - mu);
+        const float rstd = rsqrtf(wave_sum(v) / D + eps);
+        bf16_t *o = out + ((size_t)b * L + t) * D;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int e = i * 256 + lane * 4;
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+            const float4 bb = *reinterpret_cast<const float4 *>(beta + e);
+            u32x2 r;
+            r.x = pack2((x[4 * i] - mu) * rstd * g.x + bb.x, (x[4 * i + 1] - mu) * rstd * g.y + bb.y);
+            r.y = pack2((x[4 * i + 2] - mu) * rstd * g.z + bb.z, (x[4 * i + 3] - mu) * rstd * g.w + bb.w);
+            *reinterpret_cast<u32x2 *>(o + e) = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row LayerNorm (in place), D = 768
+
+__global__ __launch_bounds__(256) void k_layernorm768(bf16_t *__restrict__ x, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float eps, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bf16_t *p = x + (size_t)r * 768;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p + i * 256 + lane * 4);
+        v[4 * i] = bf2f(w.x & 0xffffu);
+        v[4 * i + 1] = bf2f(w.x >> 16);
+        v[4 * i + 2] = bf2f(w.y & 0xffffu);
+        v[4 * i + 3] = bf2f(w.y >> 16);
+        s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
+    }
+    const float mu = wave_sum(s) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        u32x2 o;
+        o.x = pack2((v[4 * i] - mu) * rstd * g.x + b.x, (v[4 * i + 1] - mu) * rstd * g.y + b.y);
+        o.y = pack2((v[4 * i + 2] - mu) * rstd * g.z + b.z, (v[4 * i + 3] - mu) * rstd * g.w + b.w);
+        *reinterpret_cast<u32x2 *>(p + e) = o;
+    }
+}
+
+// ------------------------------------------------------------------ GEMM  C = epi(A . W^T + bias)
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+// byte offset of 16-byte chunk c (0..7) of row r inside a [rows][64 bf16] LDS tile (128-B rows), XOR-swizzled so that a
+// wave's ds_read_b128 of 16 rows x 4 chunks spreads over all bank groups
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// EPI: 0 bias, 1 bias + erf-GELU, 2 bias + residual.  M arbitrary (guarded), N % 128 == 0, K % 64 == 0.
+// The MFMA is issued as (W-fragment, A-fragment): the accumulator then holds C^T tiles -- row = n (registers), col = m
+// (lane) -- so each lane owns 4 CONSECUTIVE n of one row m and the epilogue stores 8 bytes at a time.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_nt(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
+                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                 bf16_t *__restrict__ C, int M, int N, int K)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+    constexpr int kStage = (BM + BN) * BK * 2;  // bytes per pipeline stage: A tile then W tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, c16 = lane & 15;
+    // consecutive blocks walk N fastest so that blocks resident together share the same A rows (L2 reuse of activations)
+    const int nb = N / BN;
+    const int m0 = (blockIdx.x / nb) * BM, n0 = (blockIdx.x % nb) * BN;
+
+    const int lc = tid & 7, lr = tid >> 3;  // loader: chunk 0..7, rows lr + 32*i
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 32 * i;
+            const int m = m0 + r;
+            ra[i] = (m < M) ? *reinterpret_cast<const u32x4 *>(A + (size_t)m * K + k0 + lc * 8) : u32x4{0, 0, 0, 0};
+            rb[i] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + r) * K + k0 + lc * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 32 * i;
+            *reinterpret_cast<u32x4 *>(smem + buf * kStage + lds_off(r, lc)) = ra[i];
+            *reinterpret_cast<u32x4 *>(smem + buf * kStage + BM * BK * 2 + lds_off(r, lc)) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const bf16x8 *>(smem + cur * kStage + lds_off(wm * 64 + t * 16 + c16, g + 4 * ks));
+                wf[t] = *reinterpret_cast<const bf16x8 *>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + t * 16 + c16, g + 4 * ks));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            lstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds, per (nt, mt), n = n0 + wn*64 + nt*16 + 4g + {0..3} of row m = m0 + wm*64 + mt*16 + c16
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + c16;
+            if (m >= M) continue;
+            float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
+            if (EPI == 1) {
+                v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752f));
+                v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752f));
+                v2 = 0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752f));
+                v3 = 0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752f));
+            }
+            if (EPI == 2) {
+                const u32x2 rv = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
+                v0 += bf2f(rv.x & 0xffffu);
+                v1 += bf2f(rv.x >> 16);
+                v2 += bf2f(rv.y & 0xffffu);
+                v3 += bf2f(rv.y >> 16);
+            }
+            u32x2 o;
+            o.x = pack2(v0, v1);
+            o.y = pack2(v2, v3);
+            *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention
+
+// grid = (H, B), block = NW*64.  qkv bf16 [B*L][3*H*64] (q | k | v thirds, head-major inside a third); out bf16 [B*L][H*64].
+// Dynamic LDS: K image [L][64] then V image [L][64], both 128-B rows with the chunk XOR of lds_off().
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv, const unsigned long long *__restrict__ kmask,
+                                                  bf16_t *__restrict__ out, int L, int H, float scale_log2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];
+    unsigned char *Ks = kv, *Vs = kv + (size_t)L * 128;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int ld = 3 * H * 64;
+    const bf16_t *base = qkv + (size_t)b * L * ld + h * 64;
+    const unsigned long long *km = kmask + (size_t)b * (L >> 6);
+    const int nkt = L >> 6;
+
+    // last 64-key tile that holds a valid key: nothing beyond it is staged or visited
+    int last = -1;
+    for (int t = 0; t < nkt; ++t)
+        if (km[t] != 0ull) last = t;
+    const int Lk = (last + 1) * 64;
+
+    for (int i = tid; i < Lk * 8; i += NW * 64) {
+        const int r = i >> 3, c = i & 7;
+        *reinterpret_cast<u32x4 *>(Ks + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(base + (size_t)r * ld + H * 64 + c * 8);
+        *reinterpret_cast<u32x4 *>(Vs + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(base + (size_t)r * ld + 2 * H * 64 + c * 8);
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < (L >> 4); qt += NW) {
+        const int q0 = qt * 16;
+        bf16_t *orow = out + ((size_t)b * L + q0 + c16) * (H * 64) + h * 64;
+        if (q0 >= Lk) {  // rows past the last valid token: never read as keys nor pooled; keep them finite
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<u32x2 *>(orow + dt * 16 + 4 * g) = u32x2{0u, 0u};
+            continue;
+        }
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (size_t)(q0 + c16) * ld + 32 * ks + 8 * g);
+        float mrun = -INFINITY, lrun = 0.f;
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt <= last; ++kt) {
+            const unsigned long long vm = km[kt];
+            if (vm == 0ull) continue;
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + lds_off(kt * 64 + t * 16 + c16, g + 4 * ks));
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                }
+            }
+            // s[t][r] = <K[kt*64 + 16t + 4g + r], Q[q0 + c16]>
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (vm >> (16 * t + 4 * g + r)) & 1ull;
+                    const float v = ok ? s[t][r] * scale_log2 : -INFINITY;
+                    s[t][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun, mloc);  // finite: vm != 0 guarantees a valid key in this tile
+            const float alpha = exp2f(mrun - mnew);
+            float psum = 0.f;
+            bf16x8 pb[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    p[j] = exp2f(s[2 * s2 + (j >> 2)][j & 3] - mnew);
+                    psum += p[j];
+                }
+                u32x4 pk;
+                pk.x = pack2(p[0], p[1]);
+                pk.y = pack2(p[2], p[3]);
+                pk.z = pack2(p[4], p[5]);
+                pk.w = pack2(p[6], p[7]);
+                pb[s2] = __builtin_bit_cast(bf16x8, pk);
+            }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                oacc[dt] *= alpha;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // V^T fragment: keys {32*s2 + 4g + 0..3} and {32*s2 + 16 + 4g + 0..3} of d = 16*dt + c16, fetched by the
+                    // transposing LDS read: lane 4q+p of each 16-lane group addresses row (key0 + q), 8 bytes at d-offset 4p
+                    const int qq = c16 >> 2, pp = c16 & 3;
+                    const int k0 = kt * 64 + 32 * s2 + 4 * g + qq;
+                    const int off0 = lds_off(k0, 2 * dt + (pp >> 1)) + 8 * (pp & 1);
+                    const int off1 = lds_off(k0 + 16, 2 * dt + (pp >> 1)) + 8 * (pp & 1);
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(Vs + off0));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(Vs + off1));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pb[s2], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 o;
+            o.x = pack2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+            o.y = pack2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            *reinterpret_cast<u32x2 *>(orow + dt * 16 + 4 * g) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ masked mean pool
+
+// grid = (D/256, B), block 256: sent[b][d] = sum_{valid t} tok[b][t][d] / #valid    (unixcoder_provider.py:152-154)
+__global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, const unsigned long long *__restrict__ kmask,
+                                              float *__restrict__ sent, int L, int D)
+{
+    const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long *km = kmask + (size_t)b * (L >> 6);
+    float acc = 0.f;
+    int cnt = 0;
+    for (int t64 = 0; t64 < (L >> 6); ++t64) {
+        const unsigned long long m = km[t64];
+        cnt += __popcll(m);
+        for (int j = 0; j < 64; ++j)
+            if ((m >> j) & 1ull) acc += bf2f(tok[((size_t)b * L + t64 * 64 + j) * D + d]);
+    }
+    sent[(size_t)b * D + d] = acc / (float)cnt;  // an all-pad row divides 0/0 exactly like the reference's mean
+}
+
+}  // namespace enc
+}  // namespace crh
+
+using namespace crh;
+using namespace crh::enc;
+
 extern "C" {
-int crh_gemm_bf16_bias(const void *, const void *, const float *, void *, int, int, int, int, void *)
+
+int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y, int T, int N, int K, int act, void *stream)
 {
-    return crh::fail(CRH_E_INTERNAL, "crh_gemm_bf16_bias: not implemented in this build");
+    if (!x || !w || !bias || !y) return fail(CRH_E_INVALID, "gemm: NULL pointer");
+    if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
+    if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm: act=%d (0 none, 1 gelu)", act);
+    const dim3 grid((unsigned)(ceil_div(T, BM) * (N / BN)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (act == 1)
+        hipLaunchKernelGGL(k_gemm_nt<1>, grid, dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+    else
+        hipLaunchKernelGGL(k_gemm_nt<0>, grid, dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
-int crh_gemm_bf16_bias_res_ln(const void *, const void *, const float *, const void *, const float *, const float *, float, void *, int,
-                              int, int, void *)
+
+int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual, const float *gamma,
+                              const float *beta, float eps, void *y, int T, int N, int K, void *stream)
 {
-    return crh::fail(CRH_E_INTERNAL, "crh_gemm_bf16_bias_res_ln: not implemented in this build");
+    if (!x || !w || !bias || !residual || !gamma || !beta || !y) return fail(CRH_E_INVALID, "gemm_res_ln: NULL pointer");
+    if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
+    if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_gemm_nt<2>, dim3((unsigned)(ceil_div(T, BM) * (N / BN))), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+                       (const bf16_t *)residual, (bf16_t *)y, T, N, K);
+    CRH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
-int crh_attn_fwd_varlen(const void *, const int32_t *, void *, int, int, int, void *)
+
+int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream)
 {
-    return crh::fail(CRH_E_INTERNAL, "crh_attn_fwd_varlen: not implemented in this build");
+    if (!qkv || !kmask || !out) return fail(CRH_E_INVALID, "attn: NULL pointer");
+    if (B <= 0 || H <= 0 || L <= 0 || L % 64 || L > 512) return fail(CRH_E_INVALID, "attn: B=%d L=%d H=%d (need L%%64==0, L<=512)", B, L, H);
+    const float scale_log2 = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
+    const size_t lds = (size_t)L * 256;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (L >= 256) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_attn<8>, dim3(H, B), dim3(512), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
+    } else {
+        hipLaunchKernelGGL(k_attn<4>, dim3(H, B), dim3(256), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
+    }
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
-int crh_embed_ln(const int32_t *, const void *, const void *, const void *, const float *, const float *, float, int, void *, int32_t *,
-                 int, int, int, void *)
+
+int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const void *type0, const float *gamma, const float *beta,
+                 float eps, int pad_id, void *out, uint64_t *kmask, int B, int L, int D, void *stream)
 {
-    return crh::fail(CRH_E_INTERNAL, "crh_embed_ln: not implemented in this build");
+    if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln: NULL pointer");
+    if (B <= 0 || L <= 0 || L % 64 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%64==0, D==768)", B, L, D);
+    hipLaunchKernelGGL(k_embed_ln, dim3(B), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
+                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
-int crh_masked_mean_pool(const void *, const int32_t *, float *, int, int, int, void *)
+
+int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D, void *stream)
 {
-    return crh::fail(CRH_E_INTERNAL, "crh_masked_mean_pool: not implemented in this build");
+    if (!tok || !kmask || !sent) return fail(CRH_E_INVALID, "pool: NULL pointer");
+    if (B <= 0 || L <= 0 || L % 64 || D % 256) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
+    hipLaunchKernelGGL(k_pool, dim3(D / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
+                       (const unsigned long long *)kmask, sent, L, D);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
-}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""HIP UniXcoder encoder driver.
+
+Host-side mirror of ``UniXcoder`` + ``embed_batch_sync`` (``src/lattice/providers/unixcoder_provider.py:52-215``):
+tokenise -> ids -> 12-layer post-LN encoder -> masked mean pool -> python floats.  Every tensor op of the forward
+is a hand-written HIP kernel reached through the C ABI (``crh_embed_ln``, ``crh_gemm_bf16_bias``,
+``crh_attn_fwd_varlen``, ``crh_gemm_bf16_bias_res_ln``, ``crh_masked_mean_pool``); PyTorch only owns the device
+buffers and the stream.  Differences from the reference, all deliberate:
+
+* ragged batches are right-padded with the pad id instead of raising (quirk Q1) -- padding is invisible to the
+  real tokens (position ids skip pads, pad keys are masked, the pool is masked);
+* attention is bidirectional with key masking (what the reference computed under transformers 4.x, quirk Q2);
+* texts are length-bucketed so short chunks do not pay for 512-token padding.
+"""
+
+from __future__ import annotations
+
+import json
+import math
+import os
+import re
+import zlib
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import ffi
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    vocab_size: int = 51416
+    hidden_size: int = 768
+    num_layers: int = 12
+    num_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 1026
+    type_vocab_size: int = 10
+    layer_norm_eps: float = 1e-5
+    pad_token_id: int = 1
+
+    @classmethod
+    def from_hf_json(cls, path: str) -> "EncoderConfig":
+        c = json.load(open(path))
+        return cls(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], num_layers=c["num_hidden_layers"],
+                   num_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                   max_position_embeddings=c["max_position_embeddings"], type_vocab_size=c.get("type_vocab_size", 1),
+                   layer_norm_eps=c.get("layer_norm_eps", 1e-5), pad_token_id=c.get("pad_token_id", 1))
+
+
+def synthetic_weights(cfg: EncoderConfig, seed: int) -> dict[str, np.ndarray]:
+    """Seeded stand-in weights under HF ``RobertaModel`` state-dict names (no checkpoint exists offline).  The numpy
+    Generator stream is machine-independent, so every box regenerates the same tensors."""
+    rng = np.random.default_rng(seed)
+    H, F = cfg.hidden_size, cfg.intermediate_size
+
+    def mat(n, k, std):
+        return rng.standard_normal((n, k), dtype=np.float32) * np.float32(std)
+
+    def vec(n, std, mean=0.0):
+        return rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean)
+    w = {
+        "embeddings.word_embeddings.weight": mat(cfg.vocab_size, H, 0.5),
+        "embeddings.position_embeddings.weight": mat(cfg.max_position_embeddings, H, 0.3),
+        "embeddings.token_type_embeddings.weight": mat(cfg.type_vocab_size, H, 0.1),
+        "embeddings.LayerNorm.weight": vec(H, 0.1, 1.0),
+        "embeddings.LayerNorm.bias": vec(H, 0.05),
+    }
+    w["embeddings.word_embeddings.weight"][cfg.pad_token_id] = 0.0
+    w["embeddings.position_embeddings.weight"][cfg.pad_token_id] = 0.0
+    for i in range(cfg.num_layers):
+        p = f"encoder.layer.{i}."
+        for name in ("query", "key", "value"):
+            w[p + f"attention.self.{name}.weight"] = mat(H, H, 2.0 / math.sqrt(H))
+            w[p + f"attention.self.{name}.bias"] = vec(H, 0.05)
+        w[p + "attention.output.dense.weight"] = mat(H, H, 1.0 / math.sqrt(H))
+        w[p + "attention.output.dense.bias"] = vec(H, 0.05)
+        w[p + "attention.output.LayerNorm.weight"] = vec(H, 0.1, 1.0)
+        w[p + "attention.output.LayerNorm.bias"] = vec(H, 0.05)
+        w[p + "intermediate.dense.weight"] = mat(F, H, 1.0 / math.sqrt(H))
+        w[p + "intermediate.dense.bias"] = vec(F, 0.05)
+        w[p + "output.dense.weight"] = mat(H, F, 1.0 / math.sqrt(F))
+        w[p + "output.dense.bias"] = vec(H, 0.05)
+        w[p + "output.LayerNorm.weight"] = vec(H, 0.1, 1.0)
+        w[p + "output.LayerNorm.bias"] = vec(H, 0.05)
+    return w
+
+
+_PIECES = re.compile(r"[A-Za-z_]+|\d+|\s+|[^\sA-Za-z_\d]")
+
+
+class HashTokenizer:
+    """Deterministic stand-in for the byte-level BPE tokenizer when no ``vocab.json``/``merges.txt`` is available
+    (benchmarks, tests, synthetic weights): splits identifiers / numbers / whitespace / punctuation and hashes every
+    piece into the vocabulary above the special ids.  NOT UniXcoder's vocabulary -- only the id *shape* is the same."""
+
+    cls_id, pad_id, sep_id = 0, 1, 2
+
+    def __init__(self, vocab_size: int, enc_only_id: int = 5):
+        self.vocab_size, self.enc_only_id = vocab_size, enc_only_id
+
+    def encode_body(self, text: str) -> list[int]:
+        span = self.vocab_size - 16
+        return [16 + zlib.crc32(p.encode("utf-8")) % span for p in _PIECES.findall(text)]
+
+
+class BpeTokenizer:
+    """The real thing, from LOCAL files only (``RobertaTokenizer(vocab_file, merges_file)``; never a hub name)."""
+
+    def __init__(self, directory: str):
+        from transformers import RobertaTokenizer
+        self._tok = RobertaTokenizer(os.path.join(directory, "vocab.json"), os.path.join(directory, "merges.txt"))
+        self.cls_id, self.sep_id, self.pad_id = self._tok.cls_token_id, self._tok.sep_token_id, self._tok.pad_token_id
+        eid = self._tok.convert_tokens_to_ids("<encoder-only>")          # from the vocabulary, never hard-coded
+        if eid is None or eid == self._tok.unk_token_id:
+            raise ValueError("vocab.json has no <encoder-only> token: not a UniXcoder vocabulary")
+        self.enc_only_id = eid
+
+    def encode_body(self, text: str) -> list[int]:
+        return self._tok.convert_tokens_to_ids(self._tok.tokenize(text))
+
+
+def wrap_encoder_only(tok, text: str, max_length: int = 512) -> list[int]:
+    """``UniXcoder.tokenize(mode="<encoder-only>")`` (unixcoder_provider.py:105-122): body truncated to
+    ``max_length - 4`` pieces, wrapped as [<s>, <encoder-only>, </s>] + body + [</s>]."""
+    assert max_length < 1024
+    body = tok.encode_body(text)[: max_length - 4]
+    return [tok.cls_id, tok.enc_only_id, tok.sep_id] + body + [tok.sep_id]
+
+
+def flops_per_chunk(L: int, cfg: EncoderConfig = EncoderConfig()) -> float:
+    """Algorithmic FLOPs of one chunk of L real tokens: GEMMs + attention contractions."""
+    H, F, n = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers
+    return n * (2.0 * L * (4 * H * H + 2 * H * F) + 4.0 * L * L * H)
+
+
+class HipUniXcoder:
+    """Weights resident on one GPU + the kernel driver."""
+
+    def __init__(self, weights: dict, cfg: EncoderConfig, tokenizer, device: int = 0):
+        import torch
+        if cfg.hidden_size != 768 or cfg.num_heads * 64 != cfg.hidden_size:
+            raise ValueError("the HIP encoder kernels are built for hidden 768 = 12 heads x 64")
+        ffi.lib()
+        self.cfg, self.tok, self.device = cfg, tokenizer, torch.device("cuda", device)
+        self._torch = torch
+
+        def dev(name, dtype):
+            t = weights[name]
+            t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t
+            return t.to(device=self.device, dtype=dtype).contiguous()
+        bf, f32 = torch.bfloat16, torch.float32
+        self.word = dev("embeddings.word_embeddings.weight", bf)
+        self.pos = dev("embeddings.position_embeddings.weight", bf)
+        self.type0 = dev("embeddings.token_type_embeddings.weight", bf)[0].contiguous()
+        self.emb_g, self.emb_b = dev("embeddings.LayerNorm.weight", f32), dev("embeddings.LayerNorm.bias", f32)
+        self.layers = []
+        for i in range(cfg.num_layers):
+            p = f"encoder.layer.{i}."
+            qkv_w = torch.cat([dev(p + f"attention.self.{n}.weight", bf) for n in ("query", "key", "value")], 0).contiguous()
+            qkv_b = torch.cat([dev(p + f"attention.self.{n}.bias", f32) for n in ("query", "key", "value")], 0).contiguous()
+            self.layers.append(dict(
+                qkv_w=qkv_w, qkv_b=qkv_b,
+                o_w=dev(p + "attention.output.dense.weight", bf), o_b=dev(p + "attention.output.dense.bias", f32),
+                ln1_g=dev(p + "attention.output.LayerNorm.weight", f32), ln1_b=dev(p + "attention.output.LayerNorm.bias", f32),
+                f1_w=dev(p + "intermediate.dense.weight", bf), f1_b=dev(p + "intermediate.dense.bias", f32),
+                f2_w=dev(p + "output.dense.weight", bf), f2_b=dev(p + "output.dense.bias", f32),
+                ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32)))
+
+    # ------------------------------------------------------------------ kernels
+    def forward_ids(self, ids):
+        """ids: int32 CUDA tensor [B, L], L % 64 == 0, padded with the pad id.  Returns f32 [B, 768] sentence embeddings."""
+        torch, L_ = self._torch, ffi.lib()
+        B, L = ids.shape
+        cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
+        T = B * L
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        bf = torch.bfloat16
+        x = torch.empty((T, H), dtype=bf, device=self.device)
+        x1 = torch.empty((T, H), dtype=bf, device=self.device)
+        qkv = torch.empty((T, 3 * H), dtype=bf, device=self.device)
+        ctx = torch.empty((T, H), dtype=bf, device=self.device)
+        hid = torch.empty((T, F), dtype=bf, device=self.device)
+        kmask = torch.empty((B, L // 64), dtype=torch.int64, device=self.device)
+        sent = torch.empty((B, H), dtype=torch.float32, device=self.device)
+        p = ffi._ptr
+        ffi.check(L_.crh_embed_ln(p(ids), p(self.word), p(self.pos), p(self.type0), p(self.emb_g), p(self.emb_b), cfg.layer_norm_eps,
+                                  cfg.pad_token_id, p(x), p(kmask), B, L, H, st))
+        for ly in self.layers:
+            ffi.check(L_.crh_gemm_bf16_bias(p(x), p(ly["qkv_w"]), p(ly["qkv_b"]), p(qkv), T, 3 * H, H, 0, st))
+            ffi.check(L_.crh_attn_fwd_varlen(p(qkv), p(kmask), p(ctx), B, L, cfg.num_heads, st))
+            ffi.check(L_.crh_gemm_bf16_bias_res_ln(p(ctx), p(ly["o_w"]), p(ly["o_b"]), p(x), p(ly["ln1_g"]), p(ly["ln1_b"]),
+                                                   cfg.layer_norm_eps, p(x1), T, H, H, st))
+            ffi.check(L_.crh_gemm_bf16_bias(p(x1), p(ly["f1_w"]), p(ly["f1_b"]), p(hid), T, F, H, 1, st))
+            ffi.check(L_.crh_gemm_bf16_bias_res_ln(p(hid), p(ly["f2_w"]), p(ly["f2_b"]), p(x1), p(ly["ln2_g"]), p(ly["ln2_b"]),
+                                                   cfg.layer_norm_eps, p(x), T, H, F, st))
+        ffi.check(L_.crh_masked_mean_pool(p(x), p(kmask), p(sent), B, L, H, st))
+        return sent
+
+    # ------------------------------------------------------------------ batching
+    def plan_batches(self, lengths, max_tokens: int = 32768, max_rows: int = 1024):
+        """Length-bucketed batches: rows sorted by length, each batch padded to its longest row rounded up to 64."""
+        order = np.argsort(np.asarray(lengths), kind="stable")
+        batches, cur, cur_L = [], [], 0
+        for i in order:
+            L = (int(lengths[i]) + 63) // 64 * 64
+            newL = max(cur_L, L)
+            if cur and (newL * (len(cur) + 1) > max_tokens or len(cur) >= max_rows):
+                batches.append((cur, cur_L))
+                cur, newL = [], L
+            cur.append(int(i))
+            cur_L = newL
+        if cur:
+            batches.append((cur, cur_L))
+        return batches
+
+    def embed_ids(self, id_lists, max_tokens: int = 32768):
+        """list of token-id lists (each <= 512) -> f32 CUDA tensor [n, 768] in input order."""
+        torch = self._torch
+        n = len(id_lists)
+        out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        for rows, L in self.plan_batches([len(x) for x in id_lists], max_tokens):
+            host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)
+            for r, i in enumerate(rows):
+                host[r, : len(id_lists[i])] = id_lists[i]
+            ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+            out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
+        return out
+
+    def embed_texts(self, texts, max_length: int = 512) -> list[list[float]]:
+        """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text."""
+        if not texts:
+            return []
+        ids = [wrap_encoder_only(self.tok, t, max_length) for t in texts]
+        return self.embed_ids(ids).cpu().numpy().tolist()
+
+
+_MODELS: dict = {}
+
+
+def load_unixcoder(model: str, extra: dict | None = None, device: int | None = None) -> HipUniXcoder:
+    """Process-wide singleton per (model, device), like the reference's lru-cached ``get_unixcoder_model``
+    (unixcoder_provider.py:157-174).  ``model`` is a LOCAL checkpoint directory, or -- with
+    ``extra={"synthetic_weights": seed}`` -- ignored in favour of seeded stand-in weights + the hashing tokenizer."""
+    from .settings import get_settings
+    extra = extra or {}
+    device = get_settings().hip_device if device is None else device
+    key = (model, device, extra.get("synthetic_weights"))
+    if key in _MODELS:
+        return _MODELS[key]
+    if extra.get("synthetic_weights") is not None:
+        cfg = EncoderConfig(num_layers=int(extra.get("num_layers", 12)))
+        m = HipUniXcoder(synthetic_weights(cfg, int(extra["synthetic_weights"])), cfg, HashTokenizer(cfg.vocab_size), device)
+    elif os.path.isdir(model):
+        import torch
+        cfg = EncoderConfig.from_hf_json(os.path.join(model, "config.json"))
+        st_path, bin_path = os.path.join(model, "model.safetensors"), os.path.join(model, "pytorch_model.bin")
+        if os.path.exists(st_path):
+            from safetensors.torch import load_file
+            sd = load_file(st_path)
+        elif os.path.exists(bin_path):
+            sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"{model} holds neither model.safetensors nor pytorch_model.bin")
+        sd = {k[len("roberta."):] if k.startswith("roberta.") else k: v for k, v in sd.items()}
+        m = HipUniXcoder(sd, cfg, BpeTokenizer(model), device)
+    else:
+        raise FileNotFoundError(
+            f"UniXcoder checkpoint {model!r} is not a local directory and hub downloads are unavailable: point "
+            "CODERAG_HIP_WEIGHTS (or ProviderConfig.model) at a local copy of microsoft/unixcoder-base, or pass "
+            "extra={'synthetic_weights': <seed>} for seeded stand-in weights")
+    _MODELS[key] = m
+    return m

@@ -168,19 +168,20 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
                               const float *gamma, const float *beta, float eps, void *y, int T, int N,
                               int K, void *stream);
 
-/* Bidirectional self-attention with key-padding by per-row length.  qkv [B, L, 3, H, 64] bf16
- * (as written by the QKV GEMM), out [B, L, H*64] bf16.  lengths int32 [B]. */
-int crh_attn_fwd_varlen(const void *qkv, const int32_t *lengths, void *out, int B, int L, int H,
-                        void *stream);
+/* Bidirectional self-attention with key masking.  qkv [B*L, 3*H*64] bf16 exactly as the QKV GEMM writes it
+ * (q | k | v thirds, head-major inside each), out [B*L, H*64] bf16.  kmask: uint64 [B, L/64], bit j of word t
+ * set when token 64t+j of the row is a real token (ids != pad) -- the reference's `mask` (unixcoder_provider.py:148).
+ * L % 64 == 0, L <= 512. */
+int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream);
 
-/* out[b, t, :] = LN(word[ids[b,t]] + pos[pos_id] + type[0]); pos_id = cumsum(ids != pad) * (ids != pad) + pad.
- * ids int32 [B, L]; tables bf16; out bf16 [B, L, 768].  Also writes lengths[b] = #non-pad tokens. */
+/* out[b, t, :] = LN((word[ids[b,t]] + type[0]) + pos[pos_id]); pos_id = cumsum(ids != pad) * (ids != pad) + pad.
+ * ids int32 [B, L]; tables bf16; out bf16 [B, L, 768].  Also writes kmask (see above). */
 int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const void *type0,
                  const float *gamma, const float *beta, float eps, int pad_id, void *out,
-                 int32_t *lengths, int B, int L, int D, void *stream);
+                 uint64_t *kmask, int B, int L, int D, void *stream);
 
-/* sent[b, :] = sum_{t < len_b} tok[b, t, :] / len_b  (f32 out, no L2 normalisation). */
-int crh_masked_mean_pool(const void *tok, const int32_t *lengths, float *sent, int B, int L, int D,
+/* sent[b, :] = sum over real tokens of tok[b, t, :] / #real tokens  (f32 out, no L2 normalisation). */
+int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D,
                          void *stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,140 @@
+"""CPU oracle of the UniXcoder encoder forward -- TEST INFRASTRUCTURE ONLY.
+
+Plain-torch fp32 restatement of what ``UniXcoder.forward`` computes
+(``src/lattice/providers/unixcoder_provider.py:137-155``) through HF ``RobertaModel``
+(installed ``transformers/models/roberta/modeling_roberta.py``: embeddings :56-121, self-attention
+:158-183, output/LN :329-340, FFN :372-398): post-LN encoder, bidirectional attention with
+key-padding masking (quirk Q2: NOT causal), erf-GELU, masked mean pooling without L2 normalisation.
+
+Pinned in this container against ``transformers.RobertaModel`` itself on seeded random weights
+(tools/gen_encoder_goldens.py -> tests/golden/encoder_*.npz).  No UniXcoder checkpoint exists offline,
+so parity with the *published weights* is unpinned; parity of the *computation* is pinned.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    """RoBERTa-base geometry = microsoft/unixcoder-base (values recalled from its public config.json; a local
+    checkpoint's config.json overrides them when one is supplied)."""
+
+    vocab_size: int = 51416
+    hidden_size: int = 768
+    num_layers: int = 12
+    num_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 1026
+    type_vocab_size: int = 10
+    layer_norm_eps: float = 1e-5
+    pad_token_id: int = 1
+
+
+def random_weights(cfg: EncoderConfig, seed: int) -> dict[str, np.ndarray]:
+    """Seeded weights under HF ``RobertaModel`` state-dict names.  numpy's Generator stream is identical on every
+    machine, so the GPU box regenerates these bit-for-bit.  Scales are chosen so activations stay O(1) through
+    12 post-LN layers (std 0.02 like HF init would make attention nearly uniform and hide softmax bugs)."""
+    rng = np.random.default_rng(seed)
+    H, F = cfg.hidden_size, cfg.intermediate_size
+
+    def mat(n, k, std):
+        return (rng.standard_normal((n, k), dtype=np.float32) * np.float32(std))
+
+    def vec(n, std, mean=0.0):
+        return (rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean))
+    w = {
+        "embeddings.word_embeddings.weight": mat(cfg.vocab_size, H, 0.5),
+        "embeddings.position_embeddings.weight": mat(cfg.max_position_embeddings, H, 0.3),
+        "embeddings.token_type_embeddings.weight": mat(cfg.type_vocab_size, H, 0.1),
+        "embeddings.LayerNorm.weight": vec(H, 0.1, 1.0),
+        "embeddings.LayerNorm.bias": vec(H, 0.05),
+    }
+    w["embeddings.word_embeddings.weight"][cfg.pad_token_id] = 0.0          # nn.Embedding padding_idx rows are zero
+    w["embeddings.position_embeddings.weight"][cfg.pad_token_id] = 0.0
+    for i in range(cfg.num_layers):
+        p = f"encoder.layer.{i}."
+        for name in ("query", "key", "value"):
+            w[p + f"attention.self.{name}.weight"] = mat(H, H, 2.0 / math.sqrt(H))
+            w[p + f"attention.self.{name}.bias"] = vec(H, 0.05)
+        w[p + "attention.output.dense.weight"] = mat(H, H, 1.0 / math.sqrt(H))
+        w[p + "attention.output.dense.bias"] = vec(H, 0.05)
+        w[p + "attention.output.LayerNorm.weight"] = vec(H, 0.1, 1.0)
+        w[p + "attention.output.LayerNorm.bias"] = vec(H, 0.05)
+        w[p + "intermediate.dense.weight"] = mat(F, H, 1.0 / math.sqrt(H))
+        w[p + "intermediate.dense.bias"] = vec(F, 0.05)
+        w[p + "output.dense.weight"] = mat(H, F, 1.0 / math.sqrt(F))
+        w[p + "output.dense.bias"] = vec(H, 0.05)
+        w[p + "output.LayerNorm.weight"] = vec(H, 0.1, 1.0)
+        w[p + "output.LayerNorm.bias"] = vec(H, 0.05)
+    return w
+
+
+def position_ids(ids: torch.Tensor, pad: int) -> torch.Tensor:
+    """modeling_roberta.py create_position_ids_from_input_ids: cumsum(ids != pad) * (ids != pad) + pad."""
+    mask = ids.ne(pad).to(torch.int64)
+    return torch.cumsum(mask, dim=1) * mask + pad
+
+
+def _ln(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray, return_tokens: bool = False,
+            dtype: torch.dtype = torch.float32):
+    """ids: int [B, L], right- or arbitrarily padded with cfg.pad_token_id.  Returns sentence embeddings [B, H]
+    (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155."""
+    W = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in weights.items()}
+    ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64))
+    B, L = ids_t.shape
+    H, nh = cfg.hidden_size, cfg.num_heads
+    dh = H // nh
+    mask = ids_t.ne(cfg.pad_token_id)
+    with torch.no_grad():
+        x = W["embeddings.word_embeddings.weight"][ids_t] + W["embeddings.token_type_embeddings.weight"][0]
+        x = x + W["embeddings.position_embeddings.weight"][position_ids(ids_t, cfg.pad_token_id)]
+        x = _ln(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], cfg.layer_norm_eps)
+        neg = torch.finfo(dtype).min
+        key_bias = torch.where(mask, 0.0, neg).to(dtype)[:, None, None, :]          # additive, on keys only
+        for i in range(cfg.num_layers):
+            p = f"encoder.layer.{i}."
+
+            def lin(t, name):
+                return t @ W[p + name + ".weight"].T + W[p + name + ".bias"]
+            q = lin(x, "attention.self.query").view(B, L, nh, dh).transpose(1, 2)
+            k = lin(x, "attention.self.key").view(B, L, nh, dh).transpose(1, 2)
+            v = lin(x, "attention.self.value").view(B, L, nh, dh).transpose(1, 2)
+            s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + key_bias
+            ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
+            x = _ln(lin(ctx, "attention.output.dense") + x, W[p + "attention.output.LayerNorm.weight"],
+                    W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
+            h = lin(x, "intermediate.dense")
+            h = h * 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0)))
+            x = _ln(lin(h, "output.dense") + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"],
+                    cfg.layer_norm_eps)
+        m = mask.to(dtype)
+        sent = (x * m[..., None]).sum(1) / m.sum(-1)[..., None]
+    return (sent.numpy(), x.numpy()) if return_tokens else sent.numpy()
+
+
+def synthetic_ids(cfg: EncoderConfig, lengths, seed: int, enc_only_id: int = 5, pad_to: int | None = None) -> np.ndarray:
+    """Token ids shaped like UniXcoder.tokenize output (unixcoder_provider.py:108-122): [<s>=0, <encoder-only>, </s>=2]
+    + body + [</s>=2], body uniform over the vocabulary minus the specials; right-padded with the pad id."""
+    rng = np.random.default_rng(seed)
+    lengths = [int(v) for v in lengths]
+    L = pad_to or max(lengths)
+    out = np.full((len(lengths), L), cfg.pad_token_id, dtype=np.int64)
+    for r, n in enumerate(lengths):
+        n = max(4, min(n, L))
+        body = rng.integers(3, cfg.vocab_size, size=n - 4)
+        out[r, :n] = np.concatenate([[0, enc_only_id, 2], body, [2]])
+    return out
