@@ -36,6 +36,7 @@ def main() -> None:
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--seed-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--embed-chunks", type=int, default=20000, help="synthetic chunks for the encoder leg (0 = skip; BASELINE C2 uses 100000)")
     ap.add_argument("--check-rows", type=int, default=200_000, help="rows of the parity subsample checked vs the oracle")
     args = ap.parse_args()
 
@@ -164,6 +165,11 @@ def main() -> None:
         "parity": parity,
     }
 
+    if args.embed_chunks > 0:
+        idx.close()
+        emb = embed_leg(np, torch, local_rank, args.embed_chunks, rank, world, dist, cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        if rank == 0:
+            out["embed"] = emb
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(np, B, K, D)
     if rank == 0:
@@ -171,6 +177,66 @@ def main() -> None:
     idx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+
+
+def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu):
+    """Second half of BASELINE.json's metric: chunks embedded/s by the HIP UniXcoder encoder (configs[1] shape:
+    synthetic chunks, lengths ~ clip(round(exp(N(ln 160, 0.8^2))), 8, 512), seeded random RoBERTa-base weights in bf16).
+    Each rank embeds its own n_chunks (weak scaling, no collective).  FLOPs are counted on TRUE lengths."""
+    from coderag_amd import encoder as drv
+    cfg = drv.EncoderConfig()
+    model = drv.HipUniXcoder(drv.synthetic_weights(cfg, 23), cfg, drv.HashTokenizer(cfg.vocab_size), local_rank)
+    rng = np.random.default_rng(1234 + rank)
+    lengths = np.clip(np.round(np.exp(rng.normal(np.log(160.0), 0.8, n_chunks))), 8, 512).astype(np.int64)
+    dev = torch.device("cuda", local_rank)
+    batches = []
+    for rows, L in model.plan_batches(lengths, max_tokens=65536):
+        host = np.full((len(rows), L), cfg.pad_token_id, dtype=np.int32)
+        for r, i in enumerate(rows):
+            n = int(lengths[i])
+            host[r, :n] = np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, n - 4), [2]]) if n >= 4 else [0, 5, 2, 2][:n]
+        batches.append(torch.from_numpy(host).to(dev))
+    for ids in batches[:3]:
+        model.forward_ids(ids)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for ids in batches:
+        model.forward_ids(ids)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    flops = float(sum(drv.flops_per_chunk(int(n), cfg) for n in lengths))
+    padded_tokens = int(sum(int(b.numel()) for b in batches))
+    res = {"metric": "chunks embedded/s (UniXcoder-geometry bf16 HIP encoder)", "value": world * n_chunks / dt, "unit": "chunks/s",
+           "chunks_per_gpu": int(n_chunks), "seconds": dt, "mean_tokens": float(lengths.mean()), "true_tokens": int(lengths.sum()),
+           "padded_tokens": padded_tokens, "batches": len(batches), "dtype": "bf16 weights/activations, f32 accumulate/LN/softmax",
+           "data": "synthetic ids + seeded random RoBERTa-base-geometry weights (no checkpoint offline)",
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops": flops}}
+    if cpu:
+        from oracle import encoder as orc
+        ocfg = orc.EncoderConfig()
+        w = orc.random_weights(ocfg, 23)
+        torch.set_num_threads(os.cpu_count())
+        sample = lengths[:24]
+        t0 = time.perf_counter()
+        for n in sample:   # single-text calls, as the reference effectively issues them (SURVEY.md quirk Q1)
+            orc.forward(w, ocfg, orc.synthetic_ids(ocfg, [int(n)], 1))
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "chunks/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"oracle/encoder.py torch-fp32 forward, {len(sample)} single-text calls "
+                                         f"(mean {float(sample.mean()):.0f} tokens), {cdt:.1f} s"}
+    return res
 
 
 def cpu_baseline(np, B, K, D):

@@ -123,6 +123,7 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
                     cfg.layer_norm_eps)
         m = mask.to(dtype)
         sent = (x * m[..., None]).sum(1) / m.sum(-1)[..., None]
+    sent, x = sent.float(), x.float()
     return (sent.numpy(), x.numpy()) if return_tokens else sent.numpy()
 
 
