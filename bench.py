@@ -22,6 +22,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (the JSON line on stdout stays alone); also keeps long runs visibly alive."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """Threads for the CPU baseline legs: the box's CPU share for one GPU is 16 cores even when more are visible."""
+    return max(1, min(16, os.cpu_count() or 1))
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -79,6 +92,7 @@ def main() -> None:
             head = xb[: min(args.check_rows, m)].cpu().numpy()
         torch.cuda.synchronize()
         del xb
+    log(f"corpus resident: {N} rows x {D} ({args.dtype})")
     qs = np.random.default_rng(7).standard_normal((B, D)).astype(np.float32)
     qd = torch.from_numpy(qs).to(dev)
     row_base = rank * N
@@ -116,6 +130,7 @@ def main() -> None:
     idx.search_finish(stream)  # also verifies no candidate buffer overflowed in any timed step
     fence()
     dt = time.perf_counter() - t0
+    log(f"search timed: {args.steps} steps in {dt:.3f} s")
     scan_ms_total, scan_launches = idx.profile()
     idx.set_profiling(False)
     stats = idx.stats()
@@ -165,6 +180,7 @@ def main() -> None:
         "parity": parity,
     }
 
+    log("parity subsample checked" if parity else "parity subsample skipped")
     if args.embed_chunks > 0:
         idx.close()
         emb = embed_leg(np, torch, local_rank, args.embed_chunks, rank, world, dist, cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
@@ -199,9 +215,11 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu):
             n = int(lengths[i])
             host[r, :n] = np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, n - 4), [2]]) if n >= 4 else [0, 5, 2, 2][:n]
         batches.append(torch.from_numpy(host).to(dev))
+    log(f"encoder leg: {n_chunks} chunks in {len(batches)} length-bucketed batches, weights resident")
     for ids in batches[:3]:
         model.forward_ids(ids)
     torch.cuda.synchronize()
+    log("encoder warm-up done")
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -215,6 +233,7 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    log(f"encoder timed: {dt:.3f} s")
     flops = float(sum(drv.flops_per_chunk(int(n), cfg) for n in lengths))
     padded_tokens = int(sum(int(b.numel()) for b in batches))
     res = {"metric": "chunks embedded/s (UniXcoder-geometry bf16 HIP encoder)", "value": world * n_chunks / dt, "unit": "chunks/s",
@@ -227,13 +246,14 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu):
         from oracle import encoder as orc
         ocfg = orc.EncoderConfig()
         w = orc.random_weights(ocfg, 23)
-        torch.set_num_threads(os.cpu_count())
+        torch.set_num_threads(host_threads())
         sample = lengths[:24]
         t0 = time.perf_counter()
         for n in sample:   # single-text calls, as the reference effectively issues them
             orc.forward(w, ocfg, orc.synthetic_ids(ocfg, [int(n)], 1))
         cdt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "chunks/s", "cores": os.cpu_count(), "kind": "port",
+        log(f"encoder CPU baseline done: {cdt:.1f} s")
+        res["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "chunks/s", "cores": host_threads(), "kind": "port",
                                "sample": f"oracle/encoder.py torch-fp32 forward, {len(sample)} single-text calls "
                                          f"(mean {float(sample.mean()):.0f} tokens), {cdt:.1f} s"}
     return res
@@ -243,20 +263,24 @@ def cpu_baseline(np, B, K, D):
     """Exact cosine top-k on the host cores with the oracle's BLAS scan (oracle/search.py:search_blas):
     the stand-in for "Qdrant exact scan" (BASELINE.md section 3).  Bounded sample: 1M rows, ~10 s."""
     from oracle import search as orc
+    from threadpoolctl import threadpool_limits
     rows = 1_000_000
+    log("search CPU baseline: generating 1M-row sample")
     rng = np.random.default_rng(20251226)
     x = rng.standard_normal((rows, D), dtype=np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     q = orc.preprocess(np.random.default_rng(7).standard_normal((B, D)).astype(np.float32))
-    orc.search_blas(x, q, K)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 10.0:
+    with threadpool_limits(limits=host_threads()):
         orc.search_blas(x, q, K)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 10.0:
+            orc.search_blas(x, q, K)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+    log("search CPU baseline done")
     return {"value": B / dt * (rows / 1e7), "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7)",
-            "cores": os.cpu_count(), "kind": "port",
+            "cores": host_threads(), "kind": "port",
             "sample": f"oracle BLAS exact scan (f32 sgemm + argpartition), {rows} rows x {B} queries top-{K}, "
                       f"{reps} batches of {dt * 1e3:.0f} ms, scaled to 10M rows"}
 

@@ -90,10 +90,19 @@ def _ln(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.
 
 
 def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray, return_tokens: bool = False,
-            dtype: torch.dtype = torch.float32):
+            dtype: torch.dtype = torch.float32, bf16_storage: bool = False):
     """ids: int [B, L], right- or arbitrarily padded with cfg.pad_token_id.  Returns sentence embeddings [B, H]
-    (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155."""
+    (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155.
+
+    ``bf16_storage=True`` keeps the arithmetic in f32 but rounds to bf16 exactly where the HIP path STORES bf16
+    (matrix weights and embedding tables, every activation written between kernels, and the softmax probabilities
+    fed to the P.V product): the model of "the same computation at the kernels' storage precision" that the GPU
+    parity test compares against.  Biases and LayerNorm parameters stay f32 there, as in the kernels."""
+    def rb(t):
+        return t.to(torch.bfloat16).to(dtype) if bf16_storage else t
     W = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in weights.items()}
+    if bf16_storage:
+        W = {k: (rb(v) if (v.ndim == 2) else v) for k, v in W.items()}
     ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64))
     B, L = ids_t.shape
     H, nh = cfg.hidden_size, cfg.num_heads
@@ -102,7 +111,7 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
     with torch.no_grad():
         x = W["embeddings.word_embeddings.weight"][ids_t] + W["embeddings.token_type_embeddings.weight"][0]
         x = x + W["embeddings.position_embeddings.weight"][position_ids(ids_t, cfg.pad_token_id)]
-        x = _ln(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], cfg.layer_norm_eps)
+        x = rb(_ln(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], cfg.layer_norm_eps))
         neg = torch.finfo(dtype).min
         key_bias = torch.where(mask, 0.0, neg).to(dtype)[:, None, None, :]          # additive, on keys only
         for i in range(cfg.num_layers):
@@ -110,17 +119,22 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
 
             def lin(t, name):
                 return t @ W[p + name + ".weight"].T + W[p + name + ".bias"]
-            q = lin(x, "attention.self.query").view(B, L, nh, dh).transpose(1, 2)
-            k = lin(x, "attention.self.key").view(B, L, nh, dh).transpose(1, 2)
-            v = lin(x, "attention.self.value").view(B, L, nh, dh).transpose(1, 2)
+            q = rb(lin(x, "attention.self.query")).view(B, L, nh, dh).transpose(1, 2)
+            k = rb(lin(x, "attention.self.key")).view(B, L, nh, dh).transpose(1, 2)
+            v = rb(lin(x, "attention.self.value")).view(B, L, nh, dh).transpose(1, 2)
             s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + key_bias
-            ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
-            x = _ln(lin(ctx, "attention.output.dense") + x, W[p + "attention.output.LayerNorm.weight"],
-                    W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
+            if bf16_storage:   # the kernel normalises AFTER the P.V product: P = exp(s - max) is what gets rounded
+                e = torch.exp(s - s.max(-1, keepdim=True).values)
+                ctx = (rb(e) @ v) / e.sum(-1, keepdim=True)
+            else:
+                ctx = torch.softmax(s, dim=-1) @ v
+            ctx = rb(ctx.transpose(1, 2).reshape(B, L, H))
+            x = rb(_ln(rb(lin(ctx, "attention.output.dense") + x), W[p + "attention.output.LayerNorm.weight"],
+                       W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps))
             h = lin(x, "intermediate.dense")
-            h = h * 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0)))
-            x = _ln(lin(h, "output.dense") + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"],
-                    cfg.layer_norm_eps)
+            h = rb(h * 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))))
+            x = rb(_ln(rb(lin(h, "output.dense") + x), W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"],
+                       cfg.layer_norm_eps))
         m = mask.to(dtype)
         sent = (x * m[..., None]).sum(1) / m.sum(-1)[..., None]
     sent, x = sent.float(), x.float()
