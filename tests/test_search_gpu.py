@@ -213,3 +213,20 @@ def test_device_io_async_and_merge(gpu):
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
     for idx in shards:
         idx.close()
+
+
+def test_sharded_index_single_rank_device_path(gpu):
+    """ShardedIndex on the device path (world 1: no collective), incl. row_base and CUDA-tensor queries."""
+    import torch
+    _ffi()
+    from coderag_amd.sharded import ShardedIndex
+    x, q = _corpus(3000, 21), _corpus(9, 22)
+    sh = ShardedIndex(768, None, shard_capacity=4096, device=0)
+    assert sh.world == 1 and sh.row_base == 0
+    sh.append_local(torch.from_numpy(x[:2000]).cuda())
+    sh.append_local(x[2000:])
+    s, r = sh.search(torch.from_numpy(q).cuda(), 20)
+    es, er = orc.cosine_search(x, q, 20, bf16=True)
+    assert np.array_equal(r.cpu().numpy(), er) and np.array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
+    assert sh.global_counts() == [3000]
+    sh.close()
