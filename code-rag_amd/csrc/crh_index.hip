@@ -137,6 +137,7 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
         CRH_TRY(dev_alloc(&h->tau, kMaxQ));
         CRH_TRY(dev_alloc(&h->qcount, kMaxQ));
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
+        CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
     }
     if (h->ws_seed < h->seed_tiles) {
         dev_free(h->gmax);
@@ -204,6 +205,7 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
                   int64_t *out_r, int slot, hipStream_t st)
 {
     const int64_t ntiles = ceil_div(h->count, kTileRows);
+    CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
     if (ntiles == 0) {
         const int64_t n = (int64_t)nq * k;
         hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out_s, out_r, n);
@@ -214,7 +216,6 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     const float margin = margin_for(h);
     SearchStatus *stt = h->status + slot;
     CRH_HIP(hipMemsetAsync(h->qcount, 0, kMaxQ * sizeof(unsigned int), st));
-    CRH_HIP(hipMemsetAsync(stt, 0, sizeof(SearchStatus), st));
 
     if (h->dtype == CRH_DTYPE_BF16)
         hipLaunchKernelGGL(k_prep_queries<true>, dim3(kMaxQ), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
@@ -227,7 +228,7 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     hipLaunchKernelGGL((k_scan<48, 0, kWaves, kRing>), dim3(scan_blocks(h, G)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
                        h->tau, mask, G, stride, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt);
     CRH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_tau, dim3(kMaxQ), dim3(256), 0, st, h->gmax, G, k, margin, h->tau);
+    hipLaunchKernelGGL(k_tau, dim3(kMaxQ), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, h->tau);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
     hipLaunchKernelGGL((k_scan<48, 1, kWaves, kRing>), dim3(scan_blocks(h, ntiles)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
@@ -568,7 +569,7 @@ int crh_index_read_rows(crh_index *h, int64_t first, int64_t n, float *out_host)
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
-    if (seed_tiles > 0) h->seed_tiles = seed_tiles;
+    if (seed_tiles > 0) h->seed_tiles = seed_tiles > 12288 ? 12288 : seed_tiles;  // k_tau keeps the sample column in LDS
     if (wave_cand_cap > 0) h->wave_cap = wave_cand_cap;
     if (query_cand_cap > 0) h->qcap = query_cand_cap;
     if (force_fallback >= 0) h->force_fallback = force_fallback;

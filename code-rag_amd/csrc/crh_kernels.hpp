@@ -233,18 +233,21 @@ template <bool ROUND_BF16>
 __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q, int nq, int dim, int ksteps,
                                                      float *__restrict__ qn, u32x4 *__restrict__ qfrag)
 {
+    __shared__ float qs[2048];
     __shared__ float dv_s;
     const int qi = blockIdx.x, tid = threadIdx.x;
     const bool real = qi < nq;
     const float *src = q + (int64_t)qi * dim;
+    for (int i = tid; i < dim; i += 64) qs[i] = real ? src[i] : 0.0f;
+    __syncthreads();
     if (tid == 0) {
-        float acc = 0.0f;
-        if (real)
-            for (int i = 0; i < dim; ++i) {
-                float v = src[i];
-                float p = v * v;
-                acc = acc + p;
-            }
+        float acc = 0.0f;  // index order, product and sum rounded separately (oracle: orc_cosine_preprocess)
+#pragma unroll 8
+        for (int i = 0; i < dim; ++i) {
+            float v = qs[i];
+            float p = v * v;
+            acc = acc + p;
+        }
         dv_s = cosine_divisor(acc);
     }
     __syncthreads();
@@ -255,12 +258,14 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q
         uint32_t hb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float x = real ? src[c8 * 8 + j] : 0.0f;
+            float x = qs[c8 * 8 + j];
             if (dv != 0.0f) x = __fdiv_rn(x, dv);
             hb[j] = f32_to_bf16_bits(x);
             v[j] = ROUND_BF16 ? bf16_bits_f32(hb[j]) : x;
-            qn[(int64_t)qi * dim + c8 * 8 + j] = v[j];
         }
+        float4 *dst = reinterpret_cast<float4 *>(qn + (int64_t)qi * dim + c8 * 8);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
         u32x4 pk;
         pk.x = hb[0] | (hb[1] << 16);
         pk.y = hb[2] | (hb[3] << 16);
@@ -447,21 +452,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 
 // k-th largest (1-based) of n keys fetched by get(i), by MSB-first 8-bit radix passes.
 // All threads of the block call it; returns the key to every thread.  Requires 1 <= k <= n.
+// hist: NT/64 sub-histograms of 256 bins (one per wave: scores of one query share their top bits, so a single
+// histogram would serialise on one or two bins); equal consecutive digits are added as one atomic.
 template <typename KeyT, int NT, typename Get>
-__device__ KeyT wg_kth_largest(Get get, unsigned int n, unsigned int k, unsigned int *hist /*256*/, unsigned int *bcast /*2*/)
+__device__ KeyT wg_kth_largest(Get get, unsigned int n, unsigned int k, unsigned int *hist /*(NT/64)*256*/, unsigned int *bcast /*2*/)
 {
     constexpr int BITS = sizeof(KeyT) * 8;
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
+    unsigned int *myhist = hist + (tid >> 6) * 256;
     KeyT prefix = 0;
     unsigned int kk = k;
     for (int shift = BITS - 8; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0u;
+        for (int i = tid; i < NW * 256; i += NT) hist[i] = 0u;
         __syncthreads();
+        unsigned int run_digit = 0xffffffffu, run_len = 0u;
         for (unsigned int i = tid; i < n; i += NT) {
             const KeyT key = get(i);
             const bool match = (shift == BITS - 8) ? true : ((key >> (shift + 8)) == prefix);
-            if (match) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+            if (match) {
+                const unsigned int d = (unsigned int)(key >> shift) & 255u;
+                if (d == run_digit) {
+                    ++run_len;
+                } else {
+                    if (run_len) atomicAdd(&myhist[run_digit], run_len);
+                    run_digit = d;
+                    run_len = 1u;
+                }
+            }
         }
+        if (run_len) atomicAdd(&myhist[run_digit], run_len);
+        __syncthreads();
+        unsigned int tot = 0u;  // fold the per-wave histograms into hist[0..255]
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += hist[w * 256 + tid];
+        }
+        __syncthreads();
+        if (tid < 256) hist[tid] = tot;
         __syncthreads();
         if (tid < 64) {
             // lane t owns bins 255-4t .. 252-4t (descending); suffix-scan across lanes
@@ -533,13 +561,15 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int G, int k, float margin,
                                              float *__restrict__ tau)
 {
-    __shared__ unsigned int hist[256];
+    extern __shared__ uint32_t col[];  // [G] ordered keys of this query's tile maxima
+    __shared__ unsigned int hist[4 * 256];
     __shared__ unsigned int bcast[2];
     const int q = blockIdx.x;
     float t = -INFINITY;
     if (G >= k) {
-        const uint32_t key = wg_kth_largest<uint32_t, 256>(
-            [&](unsigned int i) { return ord_f32(gmax[(size_t)i * 64 + q]); }, (unsigned int)G, (unsigned int)k, hist, bcast);
+        for (int i = threadIdx.x; i < G; i += 256) col[i] = ord_f32(gmax[(size_t)i * 64 + q]);
+        __syncthreads();
+        const uint32_t key = wg_kth_largest<uint32_t, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k, hist, bcast);
         t = unord_f32(key);
         if (t > -INFINITY) t = t - margin;
     }
@@ -609,9 +639,11 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
                                                   int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
 {
     constexpr int NT = 1024;
+    constexpr unsigned int LCAP = 2048;  // survivors kept in LDS (the normal case: ~k + a few)
     __shared__ float qv[2048];
+    __shared__ unsigned long long lkeys[LCAP];
     __shared__ unsigned long long sortbuf[CRH_MAX_K];
-    __shared__ unsigned int hist[256];
+    __shared__ unsigned int hist[(NT / 64) * 256];
     __shared__ unsigned int bcast[2];
     __shared__ unsigned int scount;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -645,19 +677,45 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
         const u32x2 e = ql[i];
         if (bits_f32(e.x) >= lower) {
             const unsigned int p = atomicAdd(&scount, 1u);
+            if (p < LCAP) lkeys[p] = (unsigned long long)e.y;
             sk[p] = (unsigned long long)e.y;
         }
     }
     __syncthreads();
     const unsigned int Ms = scount;
+    const bool in_lds = Ms <= LCAP;
     for (unsigned int p = tid; p < Ms; p += NT) {
-        const uint32_t row = (uint32_t)sk[p];
+        const uint32_t row = (uint32_t)(in_lds ? lkeys[p] : sk[p]);
         const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv);
-        sk[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+        const unsigned long long key = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+        if (in_lds)
+            lkeys[p] = key;
+        else
+            sk[p] = key;
     }
     __syncthreads();
-
     const unsigned int k2 = (unsigned int)k < Ms ? (unsigned int)k : Ms;
+
+    if (in_lds) {
+        // keys are unique (distinct rows): the rank of a key is the number of larger keys -- counted from LDS
+        // broadcast reads, no barriers, no sort
+        for (unsigned int p = tid; p < Ms; p += NT) {
+            const unsigned long long key = lkeys[p];
+            unsigned int rank = 0u;
+            for (unsigned int j = 0; j < Ms; ++j) rank += (lkeys[j] > key) ? 1u : 0u;
+            if (rank < k2) {
+                os[rank] = unord_f32((uint32_t)(key >> 32));
+                orow[rank] = row_base + (int64_t)(uint32_t)(~(uint32_t)key);
+            }
+        }
+        for (unsigned int i = k2 + tid; i < (unsigned int)k; i += NT) {
+            os[i] = -INFINITY;
+            orow[i] = -1;
+        }
+        return;
+    }
+
+    // general path (more survivors than LDS holds: massive ties / duplicates): 64-bit radix select + sort of the top k
     const unsigned long long kkey =
         wg_kth_largest<unsigned long long, NT>([&](unsigned int i) { return sk[i]; }, Ms, k2, hist, bcast);
     int P = 1;
