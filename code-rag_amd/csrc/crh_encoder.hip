@@ -14,7 +14,9 @@
 //                 MFMA with the softmax statistics lane-local (query on the lane), V consumed through
 //                 ds_read_b64_tr_b16 so it is never transposed in memory; keys masked by the validity bitmask
 //   k_pool        masked mean over valid tokens (f32 out, no L2 normalisation)
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "crh_common.h"
 
@@ -36,6 +38,22 @@ __device__ __forceinline__ unsigned int f2bf(float x)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+
+// erf-GELU, x * Phi(x), with Phi from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16's 2^-9): one v_exp, one
+// v_rcp and a degree-5 Horner chain instead of libm's branchy erff (the FFN1 epilogue evaluates 64 of these per lane
+// per tile: erff made that GEMM ~35 % slower than its FLOPs warrant).  For x < 0 the tail itself is Phi(x): no cancellation.
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float tail = 0.5f * poly * t * __expf(-ax * ax);   // = 1 - Phi(|x|)
+    return x * (x >= 0.f ? 1.0f - tail : tail);
+}
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -147,110 +165,239 @@ __global__ __launch_bounds__(256) void k_layernorm768(bf16_t *__restrict__ x, co
 
 // ------------------------------------------------------------------ GEMM  C = epi(A . W^T + bias)
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 256, BN = 128, BK = 64, STAGES = 3, GEMM_WAVES = 8;
 
 // byte offset of 16-byte chunk c (0..7) of row r inside a [rows][64 bf16] LDS tile (128-B rows), XOR-swizzled so that a
-// wave's ds_read_b128 of 16 rows x 4 chunks spreads over all bank groups
+// wave's ds_read_b128 of 16 rows x 4 chunks spreads over all 16 slots of the 256-B bank row (conflict-free)
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
 // EPI: 0 bias, 1 bias + erf-GELU, 2 bias + residual.  M arbitrary (guarded), N % 128 == 0, K % 64 == 0.
-// The MFMA is issued as (W-fragment, A-fragment): the accumulator then holds C^T tiles -- row = n (registers), col = m
-// (lane) -- so each lane owns 4 CONSECUTIVE n of one row m and the epilogue stores 8 bytes at a time.
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_nt(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
-                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                 bf16_t *__restrict__ C, int M, int N, int K)
+// 256x128x64 tiles, 8 waves (4 along M x 2 along N, 64x64 each), one workgroup per CU.
+//  * Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KiB = 8 tile rows straight into LDS
+//    (destination = wave-uniform base + lane*16, a lane-linear image); the XOR swizzle the fragment reads expect is applied
+//    to the per-lane SOURCE chunk.  No staging VGPRs, no ds_write.
+//  * 3-stage ring, ONE raw s_barrier per k-iteration, counted vmcnt: the loads of tile kt+2 are issued right after the
+//    barrier of iteration kt and stay in flight across the next barrier, so a tile has two full iterations (~1 us) to land.
+//    (With 2 stages and __syncthreads' vmcnt(0) every iteration exposed the whole L2/HBM latency: 600 TFLOP/s.)
+//  * The MFMA is issued as (W-fragment, A-fragment): the accumulator holds C^T tiles -- row = n (registers), col = m (lane)
+//    -- so each lane owns 4 CONSECUTIVE n of one row m and the epilogue stores 8 bytes at a time.
+// DBG (timing ablations only, wrong results): 1 = no LDS-DMA inside the loop, 2 = no MFMA, 3 = no fragment reads in the loop
+//
+// Persistent: the grid is 8k workgroups (<= one per CU); each walks a strided list of tiles with ONE software pipeline
+// running across tile boundaries -- while a tile's epilogue runs, the first two k-tiles of the next tile are already in
+// flight, so neither the DMA latency of a tile's first loads nor (most of) its epilogue is exposed any more
+// (measured before: ~6 us of fixed cost per 256x128 tile against ~11 us of main loop at K = 768).
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
+                                                            const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                            bf16_t *__restrict__ C, int M, int N, int K)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
-    constexpr int kStage = (BM + BN) * BK * 2;  // bytes per pipeline stage: A tile then W tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kStage = (BM + BN) * BK * 2;  // bytes per stage: A tile (256 rows) then W tile (128 rows)
+    constexpr int kPieces = (BM + BN) / 8;      // 1-KiB pieces per stage (8 rows each): 32 of A, 16 of W
+    constexpr int kPer = kPieces / GEMM_WAVES;  // LDS-DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // STAGES * kStage (the only LDS object)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, c16 = lane & 15;
-    // consecutive blocks walk N fastest so that blocks resident together share the same A rows (L2 reuse of activations)
-    const int nb = N / BN;
-    const int m0 = (blockIdx.x / nb) * BM, n0 = (blockIdx.x % nb) * BN;
 
-    const int lc = tid & 7, lr = tid >> 3;  // loader: chunk 0..7, rows lr + 32*i
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = lr + 32 * i;
-            const int m = m0 + r;
-            ra[i] = (m < M) ? *reinterpret_cast<const u32x4 *>(A + (size_t)m * K + k0 + lc * 8) : u32x4{0, 0, 0, 0};
-            rb[i] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + r) * K + k0 + lc * 8);
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with the
+    // plain order the nb column-tiles that share one 256-row A panel land on 8 different L2s and the panel is fetched from
+    // HBM/MALL up to nb times (measured: the loop was bound by exactly that re-read traffic, ~6 TB/s).  Each XCD therefore
+    // owns a contiguous run of tiles, N fastest, and its workgroups stride through that run together.
+    // (`b % 8` only labels workgroups that share an XCD; a different placement would change speed, never results.)
+    const int nb = N / BN, nk = K / BK;
+    const int tiles = ((M + BM - 1) / BM) * nb;
+    int lo, ntl;
+    const int bpx = gridDim.x >> 3;             // workgroups per XCD label
+    const int jx = blockIdx.x >> 3;
+    {
+        const int xcd = blockIdx.x & 7, q = tiles >> 3, r = tiles & 7;
+        lo = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jx;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        ntl = jx < cnt ? (cnt - jx + bpx - 1) / bpx : 0;
+    }
+    if (ntl == 0) return;                       // (before any barrier)
+    const int total = ntl * nk;
+
+    const int prow = lane >> 3, pslot = lane & 7;  // piece-local row / 16-byte slot of this lane
+    // Issue cursor: the pipeline step whose LDS-DMA pieces are being dealt out (two steps ahead of the one computed).  Its
+    // tile origin, k offset and stage are advanced incrementally -- an integer division per piece cost ~0.7 us per step.
+    int c_m0, c_n0, c_k0 = 0, c_buf = 0, c_ts = 0;
+    auto cursor_tile = [&]() {
+        const int tile = lo + c_ts * bpx;
+        c_m0 = (tile / nb) * BM;
+        c_n0 = (tile % nb) * BN;
+    };
+    cursor_tile();
+    auto cursor_advance = [&]() {
+        c_buf = (c_buf == STAGES - 1) ? 0 : c_buf + 1;
+        c_k0 += BK;
+        if (c_k0 == K) {
+            c_k0 = 0;
+            ++c_ts;
+            if (c_ts < ntl) cursor_tile();
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = lr + 32 * i;
-            *reinterpret_cast<u32x4 *>(smem + buf * kStage + lds_off(r, lc)) = ra[i];
-            *reinterpret_cast<u32x4 *>(smem + buf * kStage + BM * BK * 2 + lds_off(r, lc)) = rb[i];
+    auto stage_one = [&](int i) {
+        const int piece = wave * kPer + i;         // pieces 0..31 -> A rows, 32..47 -> W rows
+        const int r = piece * 8 + prow;            // row inside the stacked [A;W] stage image
+        const int c = pslot ^ (r & 7);             // slot s of row r holds chunk s ^ (r & 7)
+        const bf16_t *src;
+        if (piece < BM / 8) {
+            int m = c_m0 + r;
+            m = m < M ? m : M - 1;                 // rows past M are loaded from a valid row and never stored
+            src = A + (size_t)m * K + c_k0 + c * 8;
+        } else {
+            src = W + (size_t)(c_n0 + r - BM) * K + c_k0 + c * 8;
         }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(smem + c_buf * kStage + piece * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][4];  // [nt][mt]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < kPer; ++i) stage_one(i);
+    cursor_advance();
+    if (total > 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int nk = K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        for (int i = 0; i < kPer; ++i) stage_one(i);
+        cursor_advance();
+    }
+    int after_epilogue = 0;  // 0: none, 1: the previous step ended with an epilogue that issued all 8 stores, 2: fewer
+    int ts = 0, kt = -1, buf = STAGES - 1;   // compute cursor: tile-list index, k-tile and stage of step `it`
+    for (int it = 0; it < total; ++it) {
+        buf = (buf == STAGES - 1) ? 0 : buf + 1;
+        if (++kt == nk) {
+            kt = 0;
+            ++ts;
+        }
+        // vmcnt retires in issue order.  Step `it` has landed once only the kPer loads of step it+1 remain outstanding.
+        // Right after an epilogue the youngest operations are that epilogue's stores (its own loads already drained every
+        // older DMA when they were waited for), so only those -- a known 8 on a full tile -- may stay in flight.
+        if (it + 1 >= total || after_epilogue == 2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epilogue == 1)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+        after_epilogue = 0;
+        __builtin_amdgcn_s_barrier();              // ... for every wave; and everyone is done with step it-1's stage
+        const bool more = it + 2 < total;          // step it+2 goes into the stage step it-1 occupied
+        if (kt == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned char *sa = smem + buf * kStage;
+        const unsigned char *sw = sa + BM * BK * 2;
+        bf16x8 af[2][4], wf[2][4];
+        if (DBG == 3) {
+            if (it == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[0][t] = af[1][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g));
+                    wf[0][t] = wf[1][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g));
+                }
+            }
+        } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                af[t] = *reinterpret_cast<const bf16x8 *>(smem + cur * kStage + lds_off(wm * 64 + t * 16 + c16, g + 4 * ks));
-                wf[t] = *reinterpret_cast<const bf16x8 *>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + t * 16 + c16, g + 4 * ks));
+                af[0][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g));
+                wf[0][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g));
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0 && DBG != 3) {  // second k-step's fragments are fetched under the first k-step's MFMAs
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[1][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g + 4));
+                    wf[1][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g + 4));
+                }
+            }
+            // the 6 LDS-DMA pieces of step it+2 are dealt between the MFMA groups: issuing one costs ~60-180 cycles of this
+            // wave's issue slot, which the matrix pipe rides out on the MFMAs already queued (all 6 up front stalled it)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (DBG == 2) {
+                        asm volatile("" ::"v"(wf[ks][nt]), "v"(af[ks][mt]));
+                    } else {
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], af[ks][mt], acc[nt][mt], 0, 0, 0);
+                    }
+                }
+                if (nt < 3 && more && DBG != 1) stage_one(ks * 3 + nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) cursor_advance();
+        if (kt != nk - 1) continue;
+
+        // ---- epilogue of this tile.  A lane holds, per (nt, mt), the 4 consecutive n = n0 + wn*64 + nt*16 + 4g + {0..3} of
+        // row m = m0 + wm*64 + mt*16 + c16.  Everything it READS (bias, residual) is fetched in one batch up front (a load
+        // inside a guarded per-element branch is waited for individually: 16 dependent L2 round trips per lane); the finished
+        // bf16 tile goes through a wave-private, XOR-swizzled LDS image so that it leaves as full 128-byte rows (8 x dwordx4
+        // per lane) instead of 16 scattered 8-byte pieces.  The image lives in the stage just consumed; the next steps'
+        // stages are untouched, and the DMA that reuses this stage is issued only after the next barrier.
+        const int tile = lo + ts * bpx;
+        const int m0 = (tile / nb) * BM, n0 = (tile % nb) * BN;
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading this stage
+        unsigned char *cimg = smem + buf * kStage + wave * 4096;  // [32 rows][64 cols] bf16, both 32-row halves in turn
+        float4 bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nt * 16 + 4 * g);
+        u32x2 rv[4][4];
+        if (EPI == 2) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) {
+                    int m = m0 + wm * 64 + mt * 16 + c16;
+                    m = m < M ? m : M - 1;
+                    rv[nt][mt] = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n0 + wn * 64 + nt * 16 + 4 * g);
+                }
         }
-        if (kt + 1 < nk) {
-            lstore(cur ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: lane holds, per (nt, mt), n = n0 + wn*64 + nt*16 + 4g + {0..3} of row m = m0 + wm*64 + mt*16 + c16
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-        const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wm * 64 + mt * 16 + c16;
-            if (m >= M) continue;
-            float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
-            if (EPI == 1) {
-                v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752f));
-                v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752f));
-                v2 = 0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752f));
-                v3 = 0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752f));
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    const int mt = half * 2 + mh;
+                    float v0 = acc[nt][mt][0] + bv[nt].x, v1 = acc[nt][mt][1] + bv[nt].y, v2 = acc[nt][mt][2] + bv[nt].z,
+                          v3 = acc[nt][mt][3] + bv[nt].w;
+                    if (EPI == 1) {
+                        v0 = gelu_erf(v0);
+                        v1 = gelu_erf(v1);
+                        v2 = gelu_erf(v2);
+                        v3 = gelu_erf(v3);
+                    }
+                    if (EPI == 2) {
+                        v0 += bf2f(rv[nt][mt].x & 0xffffu);
+                        v1 += bf2f(rv[nt][mt].x >> 16);
+                        v2 += bf2f(rv[nt][mt].y & 0xffffu);
+                        v3 += bf2f(rv[nt][mt].y >> 16);
+                    }
+                    u32x2 o;
+                    o.x = pack2(v0, v1);
+                    o.y = pack2(v2, v3);
+                    const int row = mh * 16 + c16;           // row of the 32-row image
+                    const int chunk = nt * 2 + (g >> 1);     // 16-byte chunk of the 128-byte row holding cols nt*16 + 4g ..
+                    *reinterpret_cast<u32x2 *>(cimg + row * 128 + ((chunk ^ (row & 7)) << 4) + (g & 1) * 8) = o;
+                }
+            // (same wave wrote and reads: the compiler's lgkmcnt wait orders the LDS accesses; no barrier needed)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3), chunk = lane & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(cimg + row * 128 + ((chunk ^ (row & 7)) << 4));
+                const int m = m0 + wm * 64 + half * 32 + row;
+                if (m < M) *reinterpret_cast<u32x4 *>(C + (size_t)m * N + n0 + wn * 64 + chunk * 8) = v;
             }
-            if (EPI == 2) {
-                const u32x2 rv = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
-                v0 += bf2f(rv.x & 0xffffu);
-                v1 += bf2f(rv.x >> 16);
-                v2 += bf2f(rv.y & 0xffffu);
-                v3 += bf2f(rv.y >> 16);
-            }
-            u32x2 o;
-            o.x = pack2(v0, v1);
-            o.y = pack2(v2, v3);
-            *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
         }
+        after_epilogue = (m0 + BM <= M) ? 1 : 2;
     }
 }
 
@@ -408,6 +555,41 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
 using namespace crh;
 using namespace crh::enc;
 
+namespace {
+// Grid: a multiple of 8 workgroups (one XCD label each).  Default: persistent, capped at the CU count, each workgroup walking
+// several tiles with one pipeline (whole forward 9.06 vs 9.29 ms against one workgroup per tile, same process, B=256 L=128;
+// the two are within a few percent -- CODERAG_HIP_GEMM_PERSISTENT=0 selects one workgroup per tile).
+unsigned gemm_grid(int T, int N)
+{
+    static int cus = 0, persistent = -1;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus < 8) cus = 256;
+        const char *e = getenv("CODERAG_HIP_GEMM_PERSISTENT");
+        persistent = (e && e[0] == '0') ? 0 : 1;
+    }
+    const int64_t tiles = crh::ceil_div(T, BM) * (N / BN);
+    const int64_t want = persistent ? std::min<int64_t>(tiles, (cus / 8) * 8) : tiles;
+    return (unsigned)(crh::ceil_div(want, 8) * 8);
+}
+
+constexpr size_t kGemmLds = (size_t)STAGES * (BM + BN) * BK * 2;  // 144 KB of the CU's 160 KB
+
+int gemm_lds_attr()
+{
+    static bool done = false;
+    if (!done) {
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        done = true;
+    }
+    return CRH_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y, int T, int N, int K, int act, void *stream)
@@ -415,12 +597,38 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
     if (!x || !w || !bias || !y) return fail(CRH_E_INVALID, "gemm: NULL pointer");
     if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
     if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm: act=%d (0 none, 1 gelu)", act);
-    const dim3 grid((unsigned)(ceil_div(T, BM) * (N / BN)));
+    const dim3 grid(gemm_grid(T, N));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CRH_TRY(gemm_lds_attr());
     if (act == 1)
-        hipLaunchKernelGGL(k_gemm_nt<1>, grid, dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        hipLaunchKernelGGL((k_gemm_nt<1, 0>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
     else
-        hipLaunchKernelGGL(k_gemm_nt<0>, grid, dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        hipLaunchKernelGGL((k_gemm_nt<0, 0>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+// timing ablations of the GEMM main loop (tools/gemm_ablate.py); results are meaningless for variant != 0
+int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K, int variant, void *stream)
+{
+    if (!x || !w || !bias || !y || T <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "debug gemm: bad arguments");
+    const dim3 grid(gemm_grid(T, N));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CRH_TRY(gemm_lds_attr());
+#define CRH_DBG_LAUNCH(V)                                                                                                   \
+    do {                                                                                                                    \
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<0, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds)); \
+        hipLaunchKernelGGL((k_gemm_nt<0, V>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,  \
+                           (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);                                                 \
+    } while (0)
+    switch (variant) {
+    case 0: CRH_DBG_LAUNCH(0); break;
+    case 1: CRH_DBG_LAUNCH(1); break;
+    case 2: CRH_DBG_LAUNCH(2); break;
+    case 3: CRH_DBG_LAUNCH(3); break;
+    default: return fail(CRH_E_INVALID, "debug gemm: variant %d", variant);
+    }
+#undef CRH_DBG_LAUNCH
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -432,7 +640,8 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
     if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_gemm_nt<2>, dim3((unsigned)(ceil_div(T, BM) * (N / BN))), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+    CRH_TRY(gemm_lds_attr());
+    hipLaunchKernelGGL((k_gemm_nt<2, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
                        (const bf16_t *)residual, (bf16_t *)y, T, N, K);
     CRH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);

@@ -26,7 +26,7 @@ EXPORTS = (
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
-    "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
+    "crh_gemm_bf16_bias", "crh_debug_gemm_variant", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool",
 )
 
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
     L.crh_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
     L.crh_index_match_rows.argtypes = [vp, C.POINTER(Filter), i32, i64, vp, C.POINTER(i64)]
     L.crh_gemm_bf16_bias.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.crh_debug_gemm_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.crh_gemm_bf16_bias_res_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, vp]
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]

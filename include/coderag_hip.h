@@ -163,6 +163,11 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
 int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
                        int act, void *stream);
 
+/* Timing ablations of the GEMM main loop (variant 0 = the real kernel; others skip a pipeline stage and return
+ * garbage).  Development aid used by tools/gemm_ablate.py; not part of the product path. */
+int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
+                           int variant, void *stream);
+
 /* y[T, N] = LayerNorm(x @ w^T + bias + residual) * gamma + beta  (post-LN block end). N == 768. */
 int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual,
                               const float *gamma, const float *beta, float eps, void *y, int T, int N,
