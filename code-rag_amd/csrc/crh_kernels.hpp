@@ -583,19 +583,23 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
 __device__ __forceinline__ float canonical_dot_tiled(const u32x4 *__restrict__ xt, int ksteps, uint32_t row,
                                                      const float *qv)
 {
+    // A row is spread over 2*ksteps 16-byte pieces 512 B / 1 KiB apart: 96 separate HBM sectors.  They are fetched 16 at a
+    // time (independent loads, one latency per batch) and then consumed strictly in index order.
     const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31);
     float acc = 0.0f;
-    for (int s = 0; s < ksteps; ++s) {
+    for (int s0 = 0; s0 < ksteps; s0 += 8) {
+        u32x4 pk[16];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const u32x4 pk = xt[base + (size_t)s * 64 + hh * 32];
-            const float *qq = qv + s * 16 + hh * 8;
-            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+        for (int j = 0; j < 16; ++j) pk[j] = xt[base + (size_t)(s0 + (j >> 1)) * 64 + (j & 1) * 32];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float p0 = qq[2 * j] * bf16_bits_f32(w[j] & 0xffffu);
+        for (int j = 0; j < 16; ++j) {
+            const float *qq = qv + (s0 + (j >> 1)) * 16 + (j & 1) * 8;
+            const uint32_t w[4] = {pk[j].x, pk[j].y, pk[j].z, pk[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p0 = qq[2 * e] * bf16_bits_f32(w[e] & 0xffffu);
                 acc = acc + p0;
-                float p1 = qq[2 * j + 1] * bf16_bits_f32(w[j] >> 16);
+                float p1 = qq[2 * e + 1] * bf16_bits_f32(w[e] >> 16);
                 acc = acc + p1;
             }
         }
@@ -607,17 +611,23 @@ __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf3
 {
     const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
     float acc = 0.0f;
-    for (int c = 0; c < (dim >> 2); ++c) {
-        const float4 x = xr[c];
-        float p;
-        p = qv[4 * c] * x.x;
-        acc = acc + p;
-        p = qv[4 * c + 1] * x.y;
-        acc = acc + p;
-        p = qv[4 * c + 2] * x.z;
-        acc = acc + p;
-        p = qv[4 * c + 3] * x.w;
-        acc = acc + p;
+    for (int c0 = 0; c0 < (dim >> 2); c0 += 16) {   // dim % 64 == 0
+        float4 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = xr[c0 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float *qq = qv + 4 * (c0 + j);
+            float p;
+            p = qq[0] * x[j].x;
+            acc = acc + p;
+            p = qq[1] * x[j].y;
+            acc = acc + p;
+            p = qq[2] * x[j].z;
+            acc = acc + p;
+            p = qq[3] * x[j].w;
+            acc = acc + p;
+        }
     }
     return acc;
 }
@@ -639,7 +649,9 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
                                                   int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
 {
     constexpr int NT = 1024;
-    constexpr unsigned int LCAP = 2048;  // survivors kept in LDS (the normal case: ~k + a few)
+    constexpr unsigned int LCAP = 2048;   // survivors kept in LDS (the normal case: ~k + a few)
+    constexpr unsigned int SCAP = 16384;  // candidate scores kept in LDS for the selection passes (64 KB)
+    __shared__ uint32_t lscore[SCAP];
     __shared__ float qv[2048];
     __shared__ unsigned long long lkeys[LCAP];
     __shared__ unsigned long long sortbuf[CRH_MAX_K];
@@ -669,16 +681,27 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     unsigned long long *sk = skeys + (size_t)q * qcap;
     __syncthreads();
 
+    // the four radix passes and the survivor cut all re-read the candidate scores: stage them in LDS once (one batch of
+    // independent loads) instead of paying an L2 round trip per element per pass
     const unsigned int kk = (unsigned int)k < M ? (unsigned int)k : M;
-    const uint32_t akey = wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return ord_f32(bits_f32(ql[i].x)); }, M, kk, hist, bcast);
+    const bool staged = M <= SCAP;
+    if (staged) {
+#pragma unroll 4
+        for (unsigned int i = tid; i < M; i += NT) lscore[i] = ord_f32(bits_f32(ql[i].x));
+        __syncthreads();
+    }
+    const uint32_t akey = staged ? wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return lscore[i]; }, M, kk, hist, bcast)
+                                 : wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return ord_f32(bits_f32(ql[i].x)); }, M, kk, hist, bcast);
     const float lower = unord_f32(akey) - margin;
+    const uint32_t lower_key = ord_f32(lower);
 
     for (unsigned int i = tid; i < M; i += NT) {
-        const u32x2 e = ql[i];
-        if (bits_f32(e.x) >= lower) {
+        const uint32_t sc = staged ? lscore[i] : ord_f32(bits_f32(ql[i].x));
+        if (sc >= lower_key) {
+            const unsigned int row = ql[i].y;
             const unsigned int p = atomicAdd(&scount, 1u);
-            if (p < LCAP) lkeys[p] = (unsigned long long)e.y;
-            sk[p] = (unsigned long long)e.y;
+            if (p < LCAP) lkeys[p] = (unsigned long long)row;
+            sk[p] = (unsigned long long)row;
         }
     }
     __syncthreads();
