@@ -203,32 +203,54 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with the
     // plain order the nb column-tiles that share one 256-row A panel land on 8 different L2s and the panel is fetched from
-    // HBM/MALL up to nb times (measured: the loop was bound by exactly that re-read traffic, ~6 TB/s).  Each XCD therefore
-    // owns a contiguous run of tiles, N fastest, and its workgroups stride through that run together.
+    // HBM/MALL up to nb times (measured: the loop was bound by exactly that re-read traffic, ~6 TB/s).  Each XCD label
+    // therefore owns a contiguous range of A panels and its workgroups stride through that range together, in SUPER-TILES
+    // of 4 panels x 8 column tiles = 32 tiles = what the XCD's 32 CUs hold at once: ~1.5 MB of A + ~1.5 MB of W resident
+    // in the 4 MB L2, each A panel shared by 8 CUs and each W tile by 4 (with N fastest over all of N, a W of 4.7 MB --
+    // FFN1 -- cycled through the L2 once per panel).
     // (`b % 8` only labels workgroups that share an XCD; a different placement would change speed, never results.)
+    constexpr int HM = 4, WN = 8;
     const int nb = N / BN, nk = K / BK;
-    const int tiles = ((M + BM - 1) / BM) * nb;
-    int lo, ntl;
+    const int panels = (M + BM - 1) / BM;
     const int bpx = gridDim.x >> 3;             // workgroups per XCD label
-    const int jx = blockIdx.x >> 3;
+    const int jx = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const bool by_panel = panels >= 16;         // enough panels to give every XCD label its own range
+    int first, cnt;                             // this label's unit range: panels (by_panel) or tiles
     {
-        const int xcd = blockIdx.x & 7, q = tiles >> 3, r = tiles & 7;
-        lo = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jx;
-        const int cnt = q + (xcd < r ? 1 : 0);
-        ntl = jx < cnt ? (cnt - jx + bpx - 1) / bpx : 0;
+        const int units = by_panel ? panels : panels * nb;
+        const int q = units >> 3, r = units & 7;
+        first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        cnt = q + (xcd < r ? 1 : 0);
     }
+    const int my_tiles = by_panel ? cnt * nb : cnt;
+    const int ntl = jx < my_tiles ? (my_tiles - jx + bpx - 1) / bpx : 0;
     if (ntl == 0) return;                       // (before any barrier)
     const int total = ntl * nk;
+    // ts-th tile of this workgroup -> origin of the tile
+    auto tile_origin = [&](int ts, int &tm0, int &tn0) {
+        const int u = jx + ts * bpx;            // index inside the label's range
+        if (!by_panel) {
+            const int tile = first + u;
+            tm0 = (tile / nb) * BM;
+            tn0 = (tile % nb) * BN;
+            return;
+        }
+        const int gsz = HM * nb;                // tiles per full group of HM panels
+        const int sr = u / gsz, ug = u - sr * gsz;
+        const int hm = (cnt - sr * HM) < HM ? (cnt - sr * HM) : HM;
+        const int bsz = hm * WN;
+        const int sc = ug / bsz, ub = ug - sc * bsz;
+        const int wn_ = (nb - sc * WN) < WN ? (nb - sc * WN) : WN;
+        const int pm = ub / wn_, pn = ub - pm * wn_;
+        tm0 = (first + sr * HM + pm) * BM;
+        tn0 = (sc * WN + pn) * BN;
+    };
 
     const int prow = lane >> 3, pslot = lane & 7;  // piece-local row / 16-byte slot of this lane
     // Issue cursor: the pipeline step whose LDS-DMA pieces are being dealt out (two steps ahead of the one computed).  Its
     // tile origin, k offset and stage are advanced incrementally -- an integer division per piece cost ~0.7 us per step.
     int c_m0, c_n0, c_k0 = 0, c_buf = 0, c_ts = 0;
-    auto cursor_tile = [&]() {
-        const int tile = lo + c_ts * bpx;
-        c_m0 = (tile / nb) * BM;
-        c_n0 = (tile % nb) * BN;
-    };
+    auto cursor_tile = [&]() { tile_origin(c_ts, c_m0, c_n0); };
     cursor_tile();
     auto cursor_advance = [&]() {
         c_buf = (c_buf == STAGES - 1) ? 0 : c_buf + 1;
@@ -342,8 +364,8 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
         // bf16 tile goes through a wave-private, XOR-swizzled LDS image so that it leaves as full 128-byte rows (8 x dwordx4
         // per lane) instead of 16 scattered 8-byte pieces.  The image lives in the stage just consumed; the next steps'
         // stages are untouched, and the DMA that reuses this stage is issued only after the next barrier.
-        const int tile = lo + ts * bpx;
-        const int m0 = (tile / nb) * BM, n0 = (tile % nb) * BN;
+        int m0, n0;
+        tile_origin(ts, m0, n0);
         __builtin_amdgcn_s_barrier();  // every wave has finished reading this stage
         unsigned char *cimg = smem + buf * kStage + wave * 4096;  // [32 rows][64 cols] bf16, both 32-row halves in turn
         float4 bv[4];

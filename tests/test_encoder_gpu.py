@@ -23,7 +23,9 @@ def _close(torch, got, ref, rel, abs_):
     assert bool((err <= lim).all()), f"max err {err.max().item():.4g} (worst excess {(err - lim).max().item():.4g})"
 
 
-@pytest.mark.parametrize("T,N,K,act", [(384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0)])
+# T >= 3841 rows exercises the per-XCD super-tile order (>= 16 panels), smaller T the linear order; ragged T the row guards
+@pytest.mark.parametrize("T,N,K,act", [(384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0),
+                                       (5000, 2304, 768, 0), (9300, 3072, 768, 1), (4097, 768, 3072, 0)])
 def test_gemm_bias_act(gpu, T, N, K, act):
     torch, ffi, dev = _env()
     g = torch.Generator(device="cpu").manual_seed(T + N)
@@ -39,7 +41,7 @@ def test_gemm_bias_act(gpu, T, N, K, act):
     _close(torch, y, ref, rel=2 ** -7, abs_=2e-3)           # one bf16 rounding of the result + f32 accumulation order
 
 
-@pytest.mark.parametrize("T,K", [(256, 768), (100, 3072)])
+@pytest.mark.parametrize("T,K", [(256, 768), (100, 3072), (6000, 768)])
 def test_gemm_residual_layernorm(gpu, T, K):
     torch, ffi, dev = _env()
     g = torch.Generator(device="cpu").manual_seed(K)
