@@ -398,8 +398,23 @@ int crh_index_destroy(crh_index *h)
     return CRH_OK;
 }
 
+static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device, const int32_t *codes, int64_t *first_row_out,
+                       void *stream, int preprocessed);
+
 int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device, const int32_t *codes, int64_t *first_row_out,
                      void *stream)
+{
+    return append_impl(h, n, vecs, on_device, codes, first_row_out, stream, 0);
+}
+
+int crh_index_append_preprocessed(crh_index *h, int64_t n, const float *vecs, int on_device, const int32_t *codes,
+                                  int64_t *first_row_out, void *stream)
+{
+    return append_impl(h, n, vecs, on_device, codes, first_row_out, stream, 1);
+}
+
+static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device, const int32_t *codes, int64_t *first_row_out,
+                       void *stream, int preprocessed)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
     if (n < 0) return fail(CRH_E_INVALID, "n < 0");
@@ -431,9 +446,9 @@ int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device, 
         const int64_t first = h->count + off;
         const unsigned blocks = (unsigned)ceil_div(m, 32);
         if (h->dtype == CRH_DTYPE_F32)
-            hipLaunchKernelGGL(k_append<true>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32);
+            hipLaunchKernelGGL(k_append<true>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32, preprocessed);
         else
-            hipLaunchKernelGGL(k_append<false>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32);
+            hipLaunchKernelGGL(k_append<false>, dim3(blocks), dim3(256), 0, st, src, m, first, h->dim, h->ksteps, h->xt, h->xf32, preprocessed);
         CRH_HIP(hipGetLastError());
         if (csrc) {
             hipLaunchKernelGGL(k_store_codes, dim3((unsigned)ceil_div(m * h->ncols, 256)), dim3(256), 0, st, csrc, m, h->ncols, first,

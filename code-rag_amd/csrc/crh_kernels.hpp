@@ -87,7 +87,7 @@ __device__ __forceinline__ float cosine_divisor(float len2)
 template <bool KEEP_F32>
 __global__ __launch_bounds__(256) void k_append(const float *__restrict__ src, int64_t n, int64_t first_row,
                                                 int dim, int ksteps, u32x4 *__restrict__ xt,
-                                                float *__restrict__ xf32)
+                                                float *__restrict__ xf32, int preprocessed)
 {
     __shared__ float buf[32][65];
     __shared__ float divisor[32];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_append(const float *__restrict__ src, i
         }
         __syncthreads();
     }
-    if (tid < 32) divisor[tid] = cosine_divisor(acc);
+    if (tid < 32) divisor[tid] = preprocessed ? 0.0f : cosine_divisor(acc);  // restored rows are stored verbatim
     __syncthreads();
 
     const int chunks = dim >> 3;  // 16-byte bf16 chunks per row

@@ -47,3 +47,19 @@ async def get_centrality_scores(lookup: Callable[[str], Awaitable[dict[str, int]
         return {}
     answers = await asyncio.gather(*(lookup(n) for n in names), return_exceptions=True)
     return {n: a for n, a in zip(names, answers) if isinstance(a, dict)}
+
+
+async def search_and_rank_batch(vector_searcher, ranker, queries, plans, graph_contexts=None, centrality=None,
+                                limit: int = 20, language: str | None = None, project_name: str | None = None):
+    """BASELINE config 5 in one call: ONE batched corpus scan for all queries (``search_code_batch``), then the hybrid
+    re-rank of each query's merged top-k exactly as ``QueryEngine.search`` would do it one query at a time
+    (engine.py:222-260: vector limit capped at ``max_vector_results``, then ``HybridRanker.rank_results``).
+    ``queries`` are strings or ready vectors; ``plans[i]`` / ``graph_contexts[i]`` / ``centrality[i]`` belong to query i."""
+    from .query_types import GraphContext
+    cap = get_settings().max_vector_results
+    per_query = await vector_searcher.search_code_batch(queries, limit=min(limit, cap), language=language, project_name=project_name)
+    ranked = []
+    for i, hits in enumerate(per_query):
+        ctx = graph_contexts[i] if graph_contexts is not None and graph_contexts[i] is not None else GraphContext()
+        ranked.append(ranker.rank_results(plans[i], ctx, hits, (centrality[i] if centrality is not None else None)))
+    return ranked

@@ -22,7 +22,7 @@ MAX_FILTERS, MAX_K = 8, 1024
 # every symbol include/coderag_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "crh_abi_version", "crh_last_error", "crh_device_count", "crh_device_info",
-    "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_tombstone",
+    "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_append_preprocessed", "crh_index_tombstone",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     L.crh_index_create.argtypes = [i32, i32, i64, i32, i32, C.POINTER(vp)]
     L.crh_index_destroy.argtypes = [vp]
     L.crh_index_append.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
+    L.crh_index_append_preprocessed.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
     L.crh_index_tombstone.argtypes = [vp, i64, vp]
     L.crh_index_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.crh_index_clear.argtypes = [vp]
@@ -188,8 +189,9 @@ class Index:
         check(lib().crh_index_reserve(self._handle(), capacity_rows))
         self.capacity_rows = max(self.capacity_rows, (capacity_rows + 31) // 32 * 32)
 
-    def append(self, vecs, codes=None, stream: int = 0) -> int:
-        """vecs: float32 [n, dim] numpy array (host) or CUDA torch tensor.  Returns the first new row."""
+    def append(self, vecs, codes=None, stream: int = 0, preprocessed: bool = False) -> int:
+        """vecs: float32 [n, dim] numpy array (host) or CUDA torch tensor.  Returns the first new row.
+        ``preprocessed=True`` stores the rows verbatim (restoring a snapshot made with :meth:`read_rows`)."""
         if isinstance(vecs, np.ndarray):
             vecs = np.ascontiguousarray(vecs, dtype=np.float32)
             if codes is not None:
@@ -202,7 +204,8 @@ class Index:
         if codes is not None and _is_dev(codes) != _is_dev(vecs):
             raise NativeError(E_INVALID, "vecs and codes must live in the same memory space")
         first = C.c_int64(-1)
-        check(lib().crh_index_append(self._handle(), n, _ptr(vecs), _is_dev(vecs), _ptr(codes), C.byref(first), stream))
+        fn = lib().crh_index_append_preprocessed if preprocessed else lib().crh_index_append
+        check(fn(self._handle(), n, _ptr(vecs), _is_dev(vecs), _ptr(codes), C.byref(first), stream))
         return int(first.value)
 
     def tombstone(self, rows) -> None:

@@ -126,6 +126,15 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
         self.max_length = max_length
         self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="hip-unixcoder")
         self._model = None
+        # cross-call dynamic batching: concurrent _embed_impl calls -- the orchestrator indexes 3
+        # files at a time under a semaphore of 5 (pipeline/orchestrator.py:652-656, providers/base.py:148) -- are coalesced
+        # into ONE length-bucketed GPU submission instead of queueing behind each other on the single worker thread
+        self.dynamic_batching = bool(config.extra.get("dynamic_batching", True))
+        self.batch_window_s = float(config.extra.get("batch_window_ms", 2.0)) / 1e3
+        self.max_batch_texts = int(config.extra.get("max_batch_texts", 4096))
+        self._pending: list[tuple[list[str], asyncio.Future]] = []
+        self._drainer: asyncio.Task | None = None
+        self.submissions = 0                       # GPU submissions so far (observability / tests)
         logger.info("Initializing HIP UniXcoder embedding provider...")
 
     def _load(self):
@@ -145,7 +154,39 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
 
     async def _embed_impl(self, texts: list[str]) -> list[list[float]]:
         loop = asyncio.get_event_loop()
-        return await loop.run_in_executor(self._executor, self._embed_sync, list(texts))
+        if not self.dynamic_batching:
+            self.submissions += 1
+            return await loop.run_in_executor(self._executor, self._embed_sync, list(texts))
+        fut: asyncio.Future = loop.create_future()
+        self._pending.append((list(texts), fut))
+        if self._drainer is None or self._drainer.done():
+            self._drainer = loop.create_task(self._drain())
+        return await fut
+
+    async def _drain(self) -> None:
+        """Collect what arrives within the window (or until max_batch_texts), embed it in one submission, hand each caller
+        its slice back in order.  A failure is delivered to every caller of that submission (each then retries on its own)."""
+        loop = asyncio.get_event_loop()
+        while self._pending:
+            await asyncio.sleep(self.batch_window_s)
+            batch, count = [], 0
+            while self._pending and (not batch or count + len(self._pending[0][0]) <= self.max_batch_texts):
+                item = self._pending.pop(0)
+                batch.append(item)
+                count += len(item[0])
+            flat = [t for texts, _ in batch for t in texts]
+            try:
+                self.submissions += 1
+                vectors = await loop.run_in_executor(self._executor, self._embed_sync, flat)
+                pos = 0
+                for texts, fut in batch:
+                    if not fut.done():
+                        fut.set_result(vectors[pos:pos + len(texts)])
+                    pos += len(texts)
+            except Exception as e:  # noqa: BLE001
+                for _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(e)
 
     @property
     def embedding_dim(self) -> int:

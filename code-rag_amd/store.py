@@ -143,7 +143,7 @@ class _Collection:
             self.index.tombstone(np.asarray(rows, dtype=np.int64))
             self._forget(rows)
 
-    def upsert(self, ids: list[str], vectors, payloads: list[dict]) -> None:
+    def upsert(self, ids: list[str], vectors, payloads: list[dict], preprocessed: bool = False) -> None:
         n = len(ids)
         if n == 0:
             return
@@ -160,7 +160,7 @@ class _Collection:
         need = rows_now + len(keep)
         if need > self.index.capacity_rows:
             self.index.reserve(max(need, 2 * self.index.capacity_rows))
-        first = self.index.append(vecs[keep], codes if self.keys else None)
+        first = self.index.append(vecs[keep], codes if self.keys else None, preprocessed=preprocessed)
         self.remove_rows(stale)
         for j, i in enumerate(keep):
             r = first + j
@@ -169,6 +169,13 @@ class _Collection:
             self.row_of_id[str(ids[i])] = r
             for c, code in enumerate(codes[j]):
                 self.rows_by_code[c].setdefault(int(code), set()).add(r)
+
+    def snapshot(self) -> tuple[list[str], np.ndarray, list[dict]]:
+        """(ids, stored vectors, payloads) of the live points, tombstones compacted away."""
+        rows = [r for r, p in enumerate(self.payloads) if p is not None]
+        total, _ = self.index.count()
+        stored = self.index.read_rows(0, total) if total else np.zeros((0, self.index.dim), np.float32)
+        return [self.ids[r] for r in rows], stored[rows], [self.payloads[r] for r in rows]
 
     def hit(self, row: int, score: float) -> dict[str, Any]:
         return {"id": self.ids[row], "score": score, "payload": dict(self.payloads[row] or {})}
@@ -431,6 +438,52 @@ class HipVectorStore:
         except Exception as e:
             logger.warning(f"Error checking file update status: {e}")
             return True
+
+    # ------------------------------------------------------------------ persistence
+    async def save(self, directory: str) -> None:
+        """Write every collection to ``directory`` (``<name>.npz`` = ids + the STORED, already preprocessed vectors;
+        ``<name>.payloads.json``).  Stands in for the Qdrant volume the reference relies on for restarts
+        (docker-compose.yml:42-43): an indexed project can be reloaded without re-embedding."""
+        import json
+        import os
+        try:
+            def work():
+                os.makedirs(directory, exist_ok=True)
+                for name, col in self._collections.items():
+                    ids, vecs, payloads = col.snapshot()
+                    np.savez(os.path.join(directory, f"{name}.npz"), ids=np.asarray(ids, dtype=object), vectors=vecs,
+                             dtype=np.int32(col.index.dtype), dim=np.int32(col.index.dim))
+                    with open(os.path.join(directory, f"{name}.payloads.json"), "w") as f:
+                        json.dump(payloads, f)
+            await self._run(work)
+        except Exception as e:
+            raise VectorStoreError(f"Failed to save collections to {directory}", cause=e)
+
+    async def load(self, directory: str) -> None:
+        """Replace the collections' contents with a snapshot written by :meth:`save`.  Vectors are stored verbatim
+        (``crh_index_append_preprocessed``), so searches return bit-identical scores and the same ids as before."""
+        import json
+        import os
+        try:
+            await self.clear_collections()
+
+            def work():
+                for name, col in self._collections.items():
+                    path = os.path.join(directory, f"{name}.npz")
+                    if not os.path.exists(path):
+                        continue
+                    z = np.load(path, allow_pickle=True)
+                    if int(z["dim"]) != col.index.dim or int(z["dtype"]) != col.index.dtype:
+                        raise ValueError(f"snapshot of {name} is dim {int(z['dim'])} / dtype {int(z['dtype'])}, the store is "
+                                         f"dim {col.index.dim} / dtype {col.index.dtype}")
+                    with open(os.path.join(directory, f"{name}.payloads.json")) as f:
+                        payloads = json.load(f)
+                    ids = [str(i) for i in z["ids"].tolist()]
+                    for s0 in range(0, len(ids), 65536):
+                        col.upsert(ids[s0:s0 + 65536], z["vectors"][s0:s0 + 65536], payloads[s0:s0 + 65536], preprocessed=True)
+            await self._run(work)
+        except Exception as e:
+            raise VectorStoreError(f"Failed to load collections from {directory}", cause=e)
 
     async def __aenter__(self):
         await self.connect()

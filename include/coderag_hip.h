@@ -92,6 +92,12 @@ int crh_index_destroy(crh_index *h);
 int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device,
                      const int32_t *codes, int64_t *first_row_out, void *stream);
 
+/* Same, for vectors that already went through cosine_preprocess (rows read back with crh_index_read_rows): stored
+ * verbatim, so a saved index is restored bit-for-bit.  Replaces what Qdrant's on-disk volume does for the reference
+ * (docker-compose.yml:42-43). */
+int crh_index_append_preprocessed(crh_index *h, int64_t n, const float *vecs, int on_device,
+                                  const int32_t *codes, int64_t *first_row_out, void *stream);
+
 /* Mark rows deleted (they stop matching; space is not reclaimed).  rows: host int64[n].
  * Replaces the point-removal half of QdrantManager.delete (embeddings/client.py:159-169);
  * which rows a payload filter selects is resolved by the host-side payload table. */

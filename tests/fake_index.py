@@ -20,11 +20,12 @@ class FakeIndex:
     def reserve(self, capacity_rows):
         self.capacity_rows = max(self.capacity_rows, (capacity_rows + 31) // 32 * 32)
 
-    def append(self, vecs, codes=None, stream=0):
+    def append(self, vecs, codes=None, stream=0, preprocessed=False):
         vecs = np.asarray(vecs, np.float32)
         assert len(self.x) + len(vecs) <= self.capacity_rows, "append beyond capacity (store must reserve first)"
         first = len(self.x)
-        self.x = np.concatenate([self.x, orc.preprocess(vecs, to_bf16=(self.dtype == 1))]) if len(vecs) else self.x
+        new = vecs if preprocessed else orc.preprocess(vecs, to_bf16=(self.dtype == 1))
+        self.x = np.concatenate([self.x, new]) if len(vecs) else self.x
         if self.n_code_cols:
             self.codes = np.concatenate([self.codes, np.asarray(codes, np.int32).reshape(len(vecs), self.n_code_cols)])
         self.alive = np.concatenate([self.alive, np.ones(len(vecs), np.uint8)])
@@ -42,6 +43,9 @@ class FakeIndex:
             return np.full((len(q), k), -np.inf, np.float32), np.full((len(q), k), -1, np.int64)
         s, r = orc.search(self.x, q, k, alive=self.alive, codes=self.codes if self.n_code_cols else None, filters=list(filters or []))
         return s, np.where(r >= 0, r + row_base, r)
+
+    def read_rows(self, first, n):
+        return self.x[first:first + n].copy()
 
     def match_rows(self, filters=None, limit=1):
         ok = self.alive.astype(bool).copy()

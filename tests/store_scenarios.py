@@ -107,6 +107,19 @@ async def run_store_scenarios(s):
         except VectorStoreError as e:
             assert "Failed to upsert vectors to code_chunks" in str(e)
 
+        # snapshot / restore (stands in for the Qdrant volume): same ids, bit-identical scores, tombstones compacted away
+        import tempfile
+        before = await s.search("code_chunks", q.tolist(), limit=25, filters={"language": "python"})
+        live = (await s.get_collection_info("code_chunks")).points_count
+        with tempfile.TemporaryDirectory() as snap:
+            await s.save(snap)
+            await s.load(snap)
+        assert (await s.get_collection_info("code_chunks")).points_count == live
+        assert (await s.get_collection_info("code_chunks")).config["rows_appended"] == live
+        assert await s.search("code_chunks", q.tolist(), limit=25, filters={"language": "python"}) == before
+        assert await s.file_needs_update("code_chunks", "/proj/f2.py", "hash2") is False
+        assert [h["id"] for h in await s.search("summaries", vecs[1].tolist(), limit=2)] == ["s2", "s1"]
+
         await s.clear_collections()
         assert (await s.get_collection_info("code_chunks")).points_count == 0
         assert (await s.get_collection_info("summaries")).points_count == 0
