@@ -43,6 +43,7 @@ struct Pending {
 
 struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
+    int batch_q = 64;  // queries per scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -200,6 +201,26 @@ int build_mask(crh_index *h, const crh_filter *filters, int nfilt, const uint32_
     return CRH_OK;
 }
 
+// scan kernel instantiations: k-steps = dim / 16; 64 queries per pass except for dim 1536 (32: LDS)
+template <int MODE>
+int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
+                SearchStatus *stt)
+{
+#define CRH_SCAN(KS, QB)                                                                                                       \
+    hipLaunchKernelGGL((k_scan<KS, MODE, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, h->qfrag, h->tau, \
+                       mask, nitems, stride, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt)
+    switch (h->ksteps) {
+    case 24: CRH_SCAN(24, 2); break;
+    case 48: CRH_SCAN(48, 2); break;
+    case 64: CRH_SCAN(64, 2); break;
+    case 96: CRH_SCAN(96, 1); break;
+    default: return fail(CRH_E_INTERNAL, "no scan kernel for %d k-steps", h->ksteps);
+    }
+#undef CRH_SCAN
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 // one <= 64-query batch, everything enqueued on `st`
 int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
                   int64_t *out_r, int slot, hipStream_t st)
@@ -218,22 +239,18 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     CRH_HIP(hipMemsetAsync(h->qcount, 0, kMaxQ * sizeof(unsigned int), st));
 
     if (h->dtype == CRH_DTYPE_BF16)
-        hipLaunchKernelGGL(k_prep_queries<true>, dim3(kMaxQ), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
     else
-        hipLaunchKernelGGL(k_prep_queries<false>, dim3(kMaxQ), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
     CRH_HIP(hipGetLastError());
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
-    hipLaunchKernelGGL((k_scan<48, 0, kWaves, kRing>), dim3(scan_blocks(h, G)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
-                       h->tau, mask, G, stride, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt);
-    CRH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_tau, dim3(kMaxQ), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, h->tau);
+    CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
+    hipLaunchKernelGGL(k_tau, dim3(h->batch_q), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, h->tau);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
-    hipLaunchKernelGGL((k_scan<48, 1, kWaves, kRing>), dim3(scan_blocks(h, ntiles)), dim3(kWaves * 64), 0, st, h->xt, h->qfrag,
-                       h->tau, mask, (int)ntiles, 1, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt);
-    CRH_HIP(hipGetLastError());
+    CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
         hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, h->qcount, qcap, h->skeys, h->qn, h->xt,
@@ -329,7 +346,8 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
 {
     if (!out) return fail(CRH_E_INVALID, "out is NULL");
     *out = nullptr;
-    if (dim != 768) return fail(CRH_E_INVALID, "dim %d not supported: the scan kernel is built for dim 768 (UniXcoder)", dim);
+    if (dim != 384 && dim != 768 && dim != 1024 && dim != 1536)
+        return fail(CRH_E_INVALID, "dim %d not supported: scan kernels are instantiated for 384, 768 (UniXcoder, the tuned case), 1024 and 1536", dim);
     if (dtype != CRH_DTYPE_F32 && dtype != CRH_DTYPE_BF16) return fail(CRH_E_INVALID, "unknown dtype %d", dtype);
     if (capacity_rows <= 0 || capacity_rows > (1LL << 31)) return fail(CRH_E_INVALID, "capacity_rows %lld out of range", (long long)capacity_rows);
     if (n_code_cols < 0 || n_code_cols > 64) return fail(CRH_E_INVALID, "n_code_cols %d out of range", n_code_cols);
@@ -346,6 +364,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     crh_index *h = new crh_index();
     h->dim = dim;
     h->ksteps = dim / 16;
+    h->batch_q = dim > 1024 ? 32 : 64;
     h->dtype = dtype;
     h->ncols = n_code_cols;
     h->device = device;
@@ -638,8 +657,8 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
 
     const uint32_t *mask = nullptr;
     CRH_TRY(build_mask(h, filters, n_filters, &mask, st));
-    for (int q0 = 0; q0 < nq; q0 += kMaxQ) {
-        const int b = std::min(kMaxQ, nq - q0);
+    for (int q0 = 0; q0 < nq; q0 += h->batch_q) {
+        const int b = std::min(h->batch_q, nq - q0);
         if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
         Pending p{};
         p.nq = b;

@@ -286,7 +286,9 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q
 // 1-KiB query pieces from LDS and issues two 32x32x16 MFMAs (queries 0-31 and 32-63 against the
 // same 32 corpus rows).  C layout: column = lane&31 = query, rows in the 16 accumulators, so the
 // per-query threshold is one VGPR per lane and the common case costs 32 v_max + 2 compares a tile.
-template <int KSTEPS, int MODE, int WAVES, int RING>
+// QB = number of 32-query MFMA column blocks per pass: 2 (64 queries) while the query image fits LDS beside the kernel's
+// other needs (dim <= 1024), 1 (32 queries) for dim 1536.
+template <int KSTEPS, int MODE, int WAVES, int RING, int QB = 2>
 __global__ __launch_bounds__(WAVES * 64) void k_scan(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
     const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, float *__restrict__ gmax,
@@ -294,17 +296,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
     static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
-    __shared__ u32x4 qs[2 * KSTEPS * 64];
+    __shared__ u32x4 qs[QB * KSTEPS * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    for (int i = tid; i < 2 * KSTEPS * 64; i += WAVES * 64) qs[i] = qfrag[i];
+    for (int i = tid; i < QB * KSTEPS * 64; i += WAVES * 64) qs[i] = qfrag[i];
     float t0 = 0.f, t1 = 0.f;
     if (MODE == 1) {
         t0 = tau[lane & 31];
-        t1 = tau[32 + (lane & 31)];
+        t1 = QB == 2 ? tau[32 + (lane & 31)] : INFINITY;
     }
     __syncthreads();
 
@@ -330,17 +332,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
         asm volatile("" ::: "memory");
 
         f32x16 a0 = {0}, a1 = {0};
-        u32x4 b0 = qs[lane], b1 = qs[KSTEPS * 64 + lane];
+        u32x4 b0 = qs[lane], b1 = qs[(QB - 1) * KSTEPS * 64 + lane];
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // order pinned by the sched_barrier: next step's query pieces (LDS), this step's two MFMAs, then the
             // load that refills this ring slot RING steps ahead (it may belong to the wave's next tile).
             const int s1 = (s + 1 < KSTEPS) ? s + 1 : s;
             const u32x4 nb0 = qs[s1 * 64 + lane];
-            const u32x4 nb1 = qs[(KSTEPS + s1) * 64 + lane];
+            const u32x4 nb1 = qs[((QB - 1) * KSTEPS + s1) * 64 + lane];
             const bf16x8 xa = __builtin_bit_cast(bf16x8, ring[s % RING]);
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+            if (QB == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
             const int sp = s + RING;
             ring[s % RING] = (sp < KSTEPS) ? __builtin_nontemporal_load(xp + sp * 64)
                                            : __builtin_nontemporal_load(xn + (sp - KSTEPS) * 64);
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
             m1 = fmaxf(m1, __shfl_xor(m1, 32));
             if (h == 0) {
                 gmax[(size_t)i * 64 + lane] = m0;
-                gmax[(size_t)i * 64 + 32 + lane] = m1;
+                if (QB == 2) gmax[(size_t)i * 64 + 32 + lane] = m1;
             }
         } else {
             float m0 = a0[0], m1 = a1[0];
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
             if (__ballot(any) != 0ull && vmask != 0u) {
                 const uint32_t rowbase = (uint32_t)(tile * 32);
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) {
                     const float tq = qb ? t1 : t0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

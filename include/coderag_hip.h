@@ -79,7 +79,8 @@ int crh_device_info(int device, char *name_out, int name_cap, char *arch_out, in
 /* Create an empty HBM-resident cosine index.  Replaces
  * QdrantManager._create_collection_with_indexes (embeddings/client.py:93-113):
  * VectorParams(size=dim, distance=COSINE) + `n_code_cols` keyword payload indexes.
- * dim must be a multiple of 16 and <= 768*2 (768 is the tuned case). */
+ * dim: 384, 768 (UniXcoder; the tuned case), 1024 or 1536 (the reference's EMBEDDING_DIMENSIONS default,
+ * config/settings.py:53). */
 int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols, int device,
                      crh_index **out);
 int crh_index_destroy(crh_index *h);

@@ -230,3 +230,25 @@ def test_sharded_index_single_rank_device_path(gpu):
     assert np.array_equal(r.cpu().numpy(), er) and np.array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
     assert sh.global_counts() == [3000]
     sh.close()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("dim", [384, 1024, 1536])
+def test_other_embedding_dimensions(gpu, dim, bf16):
+    """1536 is the reference's EMBEDDING_DIMENSIONS default (config/settings.py:53): 32-query scan passes; 384/1024: 64."""
+    ffi = _ffi()
+    rng = np.random.default_rng(dim)
+    n = 3000
+    x = rng.standard_normal((n, dim)).astype(np.float32) * 3
+    q = rng.standard_normal((70, dim)).astype(np.float32)
+    idx = ffi.Index(dim, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n)
+    idx.append(x)
+    got = idx.read_rows(0, n)
+    assert np.array_equal(got.view(np.uint32), orc.preprocess(x, to_bf16=bf16).view(np.uint32))
+    s, r = idx.search(q, 20)
+    es, er = orc.cosine_search(x, q, 20, bf16=bf16)
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    assert idx.stats()["batches"] == (3 if dim == 1536 else 2)
+    idx.close()
+    with pytest.raises(ffi.NativeError):
+        ffi.Index(100, ffi.DTYPE_F32, 64)
