@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
     extern __shared__ int posid[];  // [L]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *row = ids + (size_t)b * L;
+    const int nw = (L + 63) >> 6;                    // mask words per row (L is a multiple of 16, not necessarily of 64)
     for (int t0 = wave * 64; t0 < L; t0 += 256) {  // validity bitmask, 64 tokens per wave step
-        const bool v = row[t0 + lane] != pad_id;
+        const bool v = (t0 + lane < L) && row[t0 + lane] != pad_id;
         const unsigned long long m = __ballot(v);
-        if (lane == 0) kmask[(size_t)b * (L >> 6) + (t0 >> 6)] = m;
+        if (lane == 0) kmask[(size_t)b * nw + (t0 >> 6)] = m;
     }
     if (tid == 0) {
         int run = 0;
@@ -432,14 +433,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
                                                   bf16_t *__restrict__ out, int L, int H, float scale_log2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kv[];
-    unsigned char *Ks = kv, *Vs = kv + (size_t)L * 128;
+    unsigned char *Ks = kv, *Vs = kv + (size_t)((L + 63) & ~63) * 128;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int ld = 3 * H * 64;
     const bf16_t *base = qkv + (size_t)b * L * ld + h * 64;
-    const unsigned long long *km = kmask + (size_t)b * (L >> 6);
-    const int nkt = L >> 6;
+    const int nkt = (L + 63) >> 6;                   // 64-key tiles; the last one may reach past L (those keys are masked)
+    const unsigned long long *km = kmask + (size_t)b * nkt;
+    const size_t last_row = (size_t)gridDim.y * L - 1;   // staging never reads past the end of the qkv buffer
 
     // last 64-key tile that holds a valid key: nothing beyond it is staged or visited
     int last = -1;
@@ -447,10 +449,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
         if (km[t] != 0ull) last = t;
     const int Lk = (last + 1) * 64;
 
+    const bf16_t *hbase = qkv + h * 64;
     for (int i = tid; i < Lk * 8; i += NW * 64) {
         const int r = i >> 3, c = i & 7;
-        *reinterpret_cast<u32x4 *>(Ks + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(base + (size_t)r * ld + H * 64 + c * 8);
-        *reinterpret_cast<u32x4 *>(Vs + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(base + (size_t)r * ld + 2 * H * 64 + c * 8);
+        size_t gr = (size_t)b * L + r;                // keys >= L belong to the next row (or nothing): loaded, never used
+        gr = gr < last_row ? gr : last_row;
+        *reinterpret_cast<u32x4 *>(Ks + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(hbase + gr * ld + H * 64 + c * 8);
+        *reinterpret_cast<u32x4 *>(Vs + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(hbase + gr * ld + 2 * H * 64 + c * 8);
     }
     __syncthreads();
 
@@ -559,10 +564,11 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
                                               float *__restrict__ sent, int L, int D)
 {
     const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long *km = kmask + (size_t)b * (L >> 6);
+    const int nw = (L + 63) >> 6;
+    const unsigned long long *km = kmask + (size_t)b * nw;
     float acc = 0.f;
     int cnt = 0;
-    for (int t64 = 0; t64 < (L >> 6); ++t64) {
+    for (int t64 = 0; t64 < nw; ++t64) {
         const unsigned long long m = km[t64];
         cnt += __popcll(m);
         for (int j = 0; j < 64; ++j)
@@ -674,11 +680,11 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
 int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream)
 {
     if (!qkv || !kmask || !out) return fail(CRH_E_INVALID, "attn: NULL pointer");
-    if (B <= 0 || H <= 0 || L <= 0 || L % 64 || L > 512) return fail(CRH_E_INVALID, "attn: B=%d L=%d H=%d (need L%%64==0, L<=512)", B, L, H);
+    if (B <= 0 || H <= 0 || L <= 0 || L % 16 || L > 512) return fail(CRH_E_INVALID, "attn: B=%d L=%d H=%d (need L%%16==0, L<=512)", B, L, H);
     const float scale_log2 = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
-    const size_t lds = (size_t)L * 256;
+    const size_t lds = (size_t)((L + 63) & ~63) * 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (L >= 256) {
+    if (L > 192) {
         static bool attr_set = false;
         if (!attr_set) {
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256));
@@ -696,7 +702,7 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
                  float eps, int pad_id, void *out, uint64_t *kmask, int B, int L, int D, void *stream)
 {
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln: NULL pointer");
-    if (B <= 0 || L <= 0 || L % 64 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%64==0, D==768)", B, L, D);
+    if (B <= 0 || L <= 0 || L % 16 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%16==0, D==768)", B, L, D);
     hipLaunchKernelGGL(k_embed_ln, dim3(B), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
                        (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D);
     CRH_HIP(hipGetLastError());
@@ -706,7 +712,7 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
 int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D, void *stream)
 {
     if (!tok || !kmask || !sent) return fail(CRH_E_INVALID, "pool: NULL pointer");
-    if (B <= 0 || L <= 0 || L % 64 || D % 256) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
+    if (B <= 0 || L <= 0 || L % 16 || D % 256) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
     hipLaunchKernelGGL(k_pool, dim3(D / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
                        (const unsigned long long *)kmask, sent, L, D);
     CRH_HIP(hipGetLastError());

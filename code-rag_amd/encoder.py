@@ -168,7 +168,7 @@ class HipUniXcoder:
 
     # ------------------------------------------------------------------ kernels
     def forward_ids(self, ids):
-        """ids: int32 CUDA tensor [B, L], L % 64 == 0, padded with the pad id.  Returns f32 [B, 768] sentence embeddings."""
+        """ids: int32 CUDA tensor [B, L], L % 16 == 0, padded with the pad id.  Returns f32 [B, 768] sentence embeddings."""
         torch, L_ = self._torch, ffi.lib()
         B, L = ids.shape
         cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
@@ -180,7 +180,7 @@ class HipUniXcoder:
         qkv = torch.empty((T, 3 * H), dtype=bf, device=self.device)
         ctx = torch.empty((T, H), dtype=bf, device=self.device)
         hid = torch.empty((T, F), dtype=bf, device=self.device)
-        kmask = torch.empty((B, L // 64), dtype=torch.int64, device=self.device)
+        kmask = torch.empty((B, (L + 63) // 64), dtype=torch.int64, device=self.device)
         sent = torch.empty((B, H), dtype=torch.float32, device=self.device)
         p = ffi._ptr
         ffi.check(L_.crh_embed_ln(p(ids), p(self.word), p(self.pos), p(self.type0), p(self.emb_g), p(self.emb_b), cfg.layer_norm_eps,
@@ -198,11 +198,12 @@ class HipUniXcoder:
 
     # ------------------------------------------------------------------ batching
     def plan_batches(self, lengths, max_tokens: int = 32768, max_rows: int = 1024):
-        """Length-bucketed batches: rows sorted by length, each batch padded to its longest row rounded up to 64."""
+        """Length-bucketed batches: rows sorted by length, each batch padded to its longest row rounded up to 16 (the
+        query-tile height of the attention kernel): ~4 % padded tokens on a mean-200 mix, against 16 % at granularity 64."""
         order = np.argsort(np.asarray(lengths), kind="stable")
         batches, cur, cur_L = [], [], 0
         for i in order:
-            L = (int(lengths[i]) + 63) // 64 * 64
+            L = (int(lengths[i]) + 15) // 16 * 16
             newL = max(cur_L, L)
             if cur and (newL * (len(cur) + 1) > max_tokens or len(cur) >= max_rows):
                 batches.append((cur, cur_L))

@@ -181,9 +181,9 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
                               int K, void *stream);
 
 /* Bidirectional self-attention with key masking.  qkv [B*L, 3*H*64] bf16 exactly as the QKV GEMM writes it
- * (q | k | v thirds, head-major inside each), out [B*L, H*64] bf16.  kmask: uint64 [B, L/64], bit j of word t
+ * (q | k | v thirds, head-major inside each), out [B*L, H*64] bf16.  kmask: uint64 [B, ceil(L/64)], bit j of word t
  * set when token 64t+j of the row is a real token (ids != pad) -- the reference's `mask` (unixcoder_provider.py:148).
- * L % 64 == 0, L <= 512. */
+ * L % 16 == 0 (padding granularity of a length bucket), L <= 512. */
 int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream);
 
 /* out[b, t, :] = LN((word[ids[b,t]] + type[0]) + pos[pos_id]); pos_id = cumsum(ids != pad) * (ids != pad) + pad.

@@ -60,13 +60,16 @@ def test_gemm_residual_layernorm(gpu, T, K):
     _close(torch, y, ref, rel=2 ** -6, abs_=2e-2)           # the pre-LN sum is held in bf16 before normalisation
 
 
-def _kmask(torch, valid):                                   # valid: bool [B, L] -> int64 [B, L/64] bit words
+def _kmask(torch, valid):                                   # valid: bool [B, L] -> int64 [B, ceil(L/64)] bit words
     B, L = valid.shape
-    w = (valid.reshape(B, L // 64, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1)
+    Lp = (L + 63) // 64 * 64
+    v = torch.zeros((B, Lp), dtype=torch.bool)
+    v[:, :L] = valid
+    w = (v.reshape(B, Lp // 64, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1)
     return w.contiguous()
 
 
-@pytest.mark.parametrize("B,L", [(3, 64), (2, 192), (4, 512)])
+@pytest.mark.parametrize("B,L", [(3, 64), (2, 192), (4, 512), (5, 16), (3, 80), (2, 208), (2, 496)])
 def test_attention(gpu, B, L):
     torch, ffi, dev = _env()
     H = 12
@@ -93,7 +96,7 @@ def test_attention(gpu, B, L):
 
 def test_embed_ln_and_pool(gpu):
     torch, ffi, dev = _env()
-    B, L, D, V, pad = 5, 128, 768, 2000, 1
+    B, L, D, V, pad = 5, 144, 768, 2000, 1
     g = torch.Generator(device="cpu").manual_seed(9)
     word = torch.randn((V, D), generator=g).to(dev, torch.bfloat16)
     pos = torch.randn((L + 2, D), generator=g).to(dev, torch.bfloat16)
@@ -101,12 +104,12 @@ def test_embed_ln_and_pool(gpu):
     gam = (1 + 0.1 * torch.randn((D,), generator=g)).to(dev)
     bet = (0.1 * torch.randn((D,), generator=g)).to(dev)
     ids = torch.randint(3, V, (B, L), generator=g, dtype=torch.int32)
-    for b, n in enumerate((128, 7, 64, 65, 100)):
+    for b, n in enumerate((144, 7, 64, 65, 100)):
         ids[b, n:] = pad
     ids[2, 10] = pad                                         # an interior pad: position ids must skip it
     ids_d = ids.to(dev)
     out = torch.empty((B, L, D), dtype=torch.bfloat16, device=dev)
-    km = torch.empty((B, L // 64), dtype=torch.int64, device=dev)
+    km = torch.empty((B, (L + 63) // 64), dtype=torch.int64, device=dev)
     ffi.check(ffi.lib().crh_embed_ln(ids_d.data_ptr(), word.data_ptr(), pos.data_ptr(), typ.data_ptr(), gam.data_ptr(), bet.data_ptr(),
                                      1e-5, pad, out.data_ptr(), km.data_ptr(), B, L, D, 0))
     valid = ids_d != pad

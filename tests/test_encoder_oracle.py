@@ -68,5 +68,5 @@ def test_length_bucketing_plan():
     seen = sorted(i for rows, _ in batches for i in rows)
     assert seen == list(range(len(lengths)))
     for rows, L in batches:
-        assert L % 64 == 0 and L >= max(lengths[i] for i in rows) and L * len(rows) <= 1024
+        assert L % 16 == 0 and L >= max(lengths[i] for i in rows) and L * len(rows) <= 1024
     assert m.plan_batches([], 1024) == []
