@@ -278,97 +278,120 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
                                          (__attribute__((address_space(3))) void *)(smem + c_buf * kStage + piece * 1024), 16, 0, 0);
     };
 
+    // ---- pipeline.  Per step (one 64-deep k-tile, two MFMA k-steps ks = 0, 1):
+    //   first half : MFMAs(it, 0) on fragments Fa (already in registers); the ks=1 fragments Fb are read underneath
+    //   middle     : lgkmcnt(0) (stage `it` fully read), counted vmcnt (stage it+1 has landed), ONE barrier
+    //   second half: MFMAs(it, 1) on Fb; underneath: the ks=0 fragments of step it+1 -> Fa, and the 6 LDS-DMA pieces of
+    //                step it+3 into the stage step `it` just vacated
+    // so every LDS read and every DMA issue sits under MFMAs of the same wave, and a stage has two steps to land.
+    // (With the barrier at the top of the step, all 16 fragment reads of all 8 waves -- 128 KiB -- hit the LDS at once
+    // behind it while the matrix pipes idled: 0.95 us per step with the DMA removed, against 0.45 of MFMA work.)
     f32x4 acc[4][4];  // [nt][mt]
+    bf16x8 Fa[4], Wa[4], Fb[4], Wb[4];
+    auto read_frags = [&](int buf_, int ks, bf16x8 (&fa_)[4], bf16x8 (&fw_)[4]) {
+        const unsigned char *sa = smem + buf_ * kStage;
+        const unsigned char *sw = sa + BM * BK * 2;
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) stage_one(i);
-    cursor_advance();
-    if (total > 1) {
+        for (int t = 0; t < 4; ++t) {
+            fa_[t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g + 4 * ks));
+            fw_[t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g + 4 * ks));
+        }
+    };
+    auto mfma_group = [&](int nt, const bf16x8 (&fa_)[4], const bf16x8 (&fw_)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (DBG == 2) {
+                asm volatile("" ::"v"(fw_[nt]), "v"(fa_[mt]));
+            } else {
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw_[nt], fa_[mt], acc[nt][mt], 0, 0, 0);
+            }
+        }
+    };
+
+    int issued = 0;
+    for (; issued < STAGES && issued < total; ++issued) {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) stage_one(i);
         cursor_advance();
     }
-    int after_epilogue = 0;  // 0: none, 1: the previous step ended with an epilogue that issued all 8 stores, 2: fewer
+    // step 0 must have landed; steps 1 and 2 (if any) may still be in flight
+    if (total >= 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPer) : "memory");
+    else if (total == 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, Fa, Wa);
+
     int ts = 0, kt = -1, buf = STAGES - 1;   // compute cursor: tile-list index, k-tile and stage of step `it`
+    int stores_before = 0;                    // stores the previous step's epilogue left in flight (8 on a full tile)
     for (int it = 0; it < total; ++it) {
         buf = (buf == STAGES - 1) ? 0 : buf + 1;
         if (++kt == nk) {
             kt = 0;
             ++ts;
         }
-        // vmcnt retires in issue order.  Step `it` has landed once only the kPer loads of step it+1 remain outstanding.
-        // Right after an epilogue the youngest operations are that epilogue's stores (its own loads already drained every
-        // older DMA when they were waited for), so only those -- a known 8 on a full tile -- may stay in flight.
-        if (it + 1 >= total || after_epilogue == 2)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after_epilogue == 1)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
-        after_epilogue = 0;
-        __builtin_amdgcn_s_barrier();              // ... for every wave; and everyone is done with step it-1's stage
-        const bool more = it + 2 < total;          // step it+2 goes into the stage step it-1 occupied
         if (kt == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const unsigned char *sa = smem + buf * kStage;
-        const unsigned char *sw = sa + BM * BK * 2;
-        bf16x8 af[2][4], wf[2][4];
-        if (DBG == 3) {
-            if (it == 0) {
+        const bool have_next = it + 1 < total;
+        const int nbuf = (buf == STAGES - 1) ? 0 : buf + 1;
+        const bool tile_end = kt == nk - 1;
+        const bool dma = issued < total;       // step it+3 exists
+
+        // ---- first half
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    af[0][t] = af[1][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g));
-                    wf[0][t] = wf[1][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[0][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g));
-                wf[0][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g));
-            }
+        for (int nt = 0; nt < 4; ++nt) {
+            mfma_group(nt, Fa, Wa);
+            if (nt == 0 && DBG != 3) read_frags(buf, 1, Fb, Wb);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 0 && DBG != 3) {  // second k-step's fragments are fetched under the first k-step's MFMAs
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    af[1][t] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 64 + t * 16 + c16, g + 4));
-                    wf[1][t] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 64 + t * 16 + c16, g + 4));
-                }
-            }
-            // the 6 LDS-DMA pieces of step it+2 are dealt between the MFMA groups: issuing one costs ~60-180 cycles of this
-            // wave's issue slot, which the matrix pipe rides out on the MFMAs already queued (all 6 up front stalled it)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    if (DBG == 2) {
-                        asm volatile("" ::"v"(wf[ks][nt]), "v"(af[ks][mt]));
-                    } else {
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], af[ks][mt], acc[nt][mt], 0, 0, 0);
-                    }
-                }
-                if (nt < 3 && more && DBG != 1) stage_one(ks * 3 + nt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // ---- middle: stage `it` is fully read; stage it+1 has landed once only what was issued after it remains outstanding
+        // (vmcnt retires in issue order): the pieces of step it+2, preceded -- right after a tile's epilogue -- by that
+        // epilogue's stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (have_next) {
+            const bool later = it + 2 < total;
+            if (later && stores_before == 8)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer + 8) : "memory");
+            else if (later)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (more) cursor_advance();
-        if (kt != nk - 1) continue;
+        stores_before = 0;
+        __builtin_amdgcn_s_barrier();
+        // ---- second half
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            mfma_group(nt, Fb, Wb);
+            if (nt == 0 && have_next && DBG != 3) read_frags(nbuf, 0, Fa, Wa);
+            if (dma && !tile_end && DBG != 1) {   // 6 pieces over the 4 groups: 2, 2, 1, 1
+                stage_one(nt < 2 ? 2 * nt : nt + 2);
+                if (nt < 2) stage_one(2 * nt + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (dma && !tile_end) {
+            cursor_advance();
+            ++issued;
+        }
+        if (!tile_end) continue;
 
         // ---- epilogue of this tile.  A lane holds, per (nt, mt), the 4 consecutive n = n0 + wn*64 + nt*16 + 4g + {0..3} of
         // row m = m0 + wm*64 + mt*16 + c16.  Everything it READS (bias, residual) is fetched in one batch up front (a load
         // inside a guarded per-element branch is waited for individually: 16 dependent L2 round trips per lane); the finished
         // bf16 tile goes through a wave-private, XOR-swizzled LDS image so that it leaves as full 128-byte rows (8 x dwordx4
-        // per lane) instead of 16 scattered 8-byte pieces.  The image lives in the stage just consumed; the next steps'
-        // stages are untouched, and the DMA that reuses this stage is issued only after the next barrier.
+        // per lane) instead of 16 scattered 8-byte pieces.  The image sits in the stage this step vacated (all reads of it
+        // completed before the middle barrier), inside the 6 KiB that THIS wave's own DMA pieces of step it+3 will overwrite
+        // -- which is why those pieces are issued after the epilogue on a tile's last step, not under its MFMAs.
         int m0, n0;
         tile_origin(ts, m0, n0);
-        __builtin_amdgcn_s_barrier();  // every wave has finished reading this stage
-        unsigned char *cimg = smem + buf * kStage + wave * 4096;  // [32 rows][64 cols] bf16, both 32-row halves in turn
+        unsigned char *cimg = smem + buf * kStage + wave * (kPer * 1024);  // [32 rows][64 cols] bf16, both halves in turn
         float4 bv[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nt * 16 + 4 * g);
@@ -420,7 +443,16 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
                 if (m < M) *reinterpret_cast<u32x4 *>(C + (size_t)m * N + n0 + wn * 64 + chunk * 8) = v;
             }
         }
-        after_epilogue = (m0 + BM <= M) ? 1 : 2;
+        stores_before = (m0 + BM <= M) ? 8 : 0;   // a ragged tile may have skipped stores: assume none are in flight
+        if (dma) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image has been read back before its stage is refilled
+            if (DBG != 1) {
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) stage_one(i);
+            }
+            cursor_advance();
+            ++issued;
+        }
     }
 }
 
