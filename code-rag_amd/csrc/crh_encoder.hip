@@ -460,7 +460,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 
 // grid = (H, B), block = NW*64.  qkv bf16 [B*L][3*H*64] (q | k | v thirds, head-major inside a third); out bf16 [B*L][H*64].
 // Dynamic LDS: K image [L][64] then V image [L][64], both 128-B rows with the chunk XOR of lds_off().
-template <int NW>
+template <int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv, const unsigned long long *__restrict__ kmask,
                                                   bf16_t *__restrict__ out, int L, int H, float scale_log2)
 {
@@ -491,75 +491,88 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
     }
     __syncthreads();
 
-    for (int qt = wave; qt < (L >> 4); qt += NW) {
-        const int q0 = qt * 16;
-        bf16_t *orow = out + ((size_t)b * L + q0 + c16) * (H * 64) + h * 64;
-        if (q0 >= Lk) {  // rows past the last valid token: never read as keys nor pooled; keep them finite
+    // Each wave works on QT 16-row query tiles AT ONCE so that every K fragment and every transposed V fragment it reads
+    // from LDS feeds QT MFMAs: with one tile per wave the kernel moved 64 B/clk/wave through an LDS that delivers
+    // 256 B/clk per CU -- LDS-bound at 8 waves by a factor of two (250 TFLOP/s at L = 512).
+    const int nqt = L >> 4;
+    for (int qg = wave; qg * QT < nqt; qg += NW) {
+        bf16x8 qf[QT][2];
+        float mrun[QT], lrun[QT];
+        f32x4 oacc[QT][4];
+        bool live[QT];                                   // tile exists and starts before the last valid key tile's end
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<u32x2 *>(orow + dt * 16 + 4 * g) = u32x2{0u, 0u};
-            continue;
+        for (int qi = 0; qi < QT; ++qi) {
+            const int q0 = (qg * QT + qi) * 16;
+            live[qi] = q0 < L && q0 < Lk;
+            const int qr = live[qi] ? q0 + c16 : 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                qf[qi][ks] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qr * ld + 32 * ks + 8 * g);
+            mrun[qi] = -INFINITY;
+            lrun[qi] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (size_t)(q0 + c16) * ld + 32 * ks + 8 * g);
-        float mrun = -INFINITY, lrun = 0.f;
-        f32x4 oacc[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int kt = 0; kt <= last; ++kt) {
             const unsigned long long vm = km[kt];
             if (vm == 0ull) continue;
-            f32x4 s[4];
+            f32x4 s[QT][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) s[qi][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + lds_off(kt * 64 + t * 16 + c16, g + 4 * ks));
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+                    for (int qi = 0; qi < QT; ++qi)
+                        s[qi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][t], 0, 0, 0);
                 }
             }
-            // s[t][r] = <K[kt*64 + 16t + 4g + r], Q[q0 + c16]>
-            float mloc = -INFINITY;
+            // s[qi][t][r] = <K[kt*64 + 16t + 4g + r], Q[q0(qi) + c16]>
+            bf16x8 pb[QT][2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int qi = 0; qi < QT; ++qi) {
+                float mloc = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (vm >> (16 * t + 4 * g + r)) & 1ull;
-                    const float v = ok ? s[t][r] * scale_log2 : -INFINITY;
-                    s[t][r] = v;
-                    mloc = fmaxf(mloc, v);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (vm >> (16 * t + 4 * g + r)) & 1ull;
+                        const float v = ok ? s[qi][t][r] * scale_log2 : -INFINITY;
+                        s[qi][t][r] = v;
+                        mloc = fmaxf(mloc, v);
+                    }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                const float mnew = fmaxf(mrun[qi], mloc);  // finite: vm != 0 guarantees a valid key in this tile
+                const float alpha = exp2f(mrun[qi] - mnew);
+                float psum = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p[j] = exp2f(s[qi][2 * s2 + (j >> 2)][j & 3] - mnew);
+                        psum += p[j];
+                    }
+                    u32x4 pk;
+                    pk.x = pack2(p[0], p[1]);
+                    pk.y = pack2(p[2], p[3]);
+                    pk.z = pack2(p[4], p[5]);
+                    pk.w = pack2(p[6], p[7]);
+                    pb[qi][s2] = __builtin_bit_cast(bf16x8, pk);
                 }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(mrun, mloc);  // finite: vm != 0 guarantees a valid key in this tile
-            const float alpha = exp2f(mrun - mnew);
-            float psum = 0.f;
-            bf16x8 pb[2];
+                psum += __shfl_xor(psum, 16);
+                psum += __shfl_xor(psum, 32);
+                lrun[qi] = lrun[qi] * alpha + psum;
+                mrun[qi] = mnew;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float p[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[j] = exp2f(s[2 * s2 + (j >> 2)][j & 3] - mnew);
-                    psum += p[j];
-                }
-                u32x4 pk;
-                pk.x = pack2(p[0], p[1]);
-                pk.y = pack2(p[2], p[3]);
-                pk.z = pack2(p[4], p[5]);
-                pk.w = pack2(p[6], p[7]);
-                pb[s2] = __builtin_bit_cast(bf16x8, pk);
+                for (int dt = 0; dt < 4; ++dt) oacc[qi][dt] *= alpha;
             }
-            psum += __shfl_xor(psum, 16);
-            psum += __shfl_xor(psum, 32);
-            lrun = lrun * alpha + psum;
-            mrun = mnew;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                oacc[dt] *= alpha;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     // V^T fragment: keys {32*s2 + 4g + 0..3} and {32*s2 + 16 + 4g + 0..3} of d = 16*dt + c16, fetched by the
@@ -574,17 +587,26 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
                         (__attribute__((address_space(3))) s16x4 *)(Vs + off1));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
                     const s16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pb[s2], oacc[dt], 0, 0, 0);
+#pragma unroll
+                    for (int qi = 0; qi < QT; ++qi)
+                        oacc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pb[qi][s2], oacc[qi][dt], 0, 0, 0);
                 }
             }
         }
-        const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            u32x2 o;
-            o.x = pack2(oacc[dt][0] * inv, oacc[dt][1] * inv);
-            o.y = pack2(oacc[dt][2] * inv, oacc[dt][3] * inv);
-            *reinterpret_cast<u32x2 *>(orow + dt * 16 + 4 * g) = o;
+        for (int qi = 0; qi < QT; ++qi) {
+            const int q0 = (qg * QT + qi) * 16;
+            if (q0 >= L) continue;                       // no such tile
+            bf16_t *orow = out + ((size_t)b * L + q0 + c16) * (H * 64) + h * 64;
+            // rows past the last valid token (not live): never read as keys nor pooled; written as zeros to stay finite
+            const float inv = (live[qi] && lrun[qi] > 0.f) ? 1.f / lrun[qi] : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 o;
+                o.x = pack2(oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv);
+                o.y = pack2(oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
+                *reinterpret_cast<u32x2 *>(orow + dt * 16 + 4 * g) = o;
+            }
         }
     }
 }
@@ -719,12 +741,12 @@ int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B
     if (L > 192) {
         static bool attr_set = false;
         if (!attr_set) {
-            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256));
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_attn<8>, dim3(H, B), dim3(512), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
+        hipLaunchKernelGGL((k_attn<8, 4>), dim3(H, B), dim3(512), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
     } else {
-        hipLaunchKernelGGL(k_attn<4>, dim3(H, B), dim3(256), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
+        hipLaunchKernelGGL((k_attn<4, 1>), dim3(H, B), dim3(256), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
     }
     CRH_HIP(hipGetLastError());
     return CRH_OK;
