@@ -22,12 +22,12 @@ def short(name: str) -> str:
 
 def main(src: str, dst: str) -> None:
     out = {"source": src, "kernels": {}, "bench_line": None}
-    log = os.path.join(src, "trace.log")
-    if os.path.exists(log):
-        for line in open(log):
+    logs = glob.glob(os.path.join(src, "**", "trace.log"), recursive=True)
+    if logs:
+        for line in open(logs[0]):
             if line.startswith("{\"metric\""):
                 out["bench_line"] = json.loads(line)
-    for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    for f in glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = out["kernels"].setdefault(short(r["Name"]), {})
             k.update(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3,
