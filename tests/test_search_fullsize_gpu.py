@@ -1,0 +1,84 @@
+"""BASELINE.json's full size (10M x 768 bf16 resident in HBM, batch-64, top-100) checked through properties that do not
+need a 10M-row CPU scan:
+  * order      : every result list is sorted by (score desc, row asc), rows unique, all rows alive;
+  * planted    : a stored row used as a query comes back first with score ~1;
+  * shards     : two 5M-row shards searched separately and merged by crh_merge_topk == the 10M-row search, bit for bit
+                 (the 8-GPU configuration in miniature);
+  * filter     : a payload filter selecting 1M of the rows == the oracle run on exactly those 1M rows;
+  * idempotent : the same search twice gives identical bytes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, D, K, NQ, BLOCK = 10_000_000, 768, 100, 64, 500_000
+
+
+def test_full_size_properties(gpu):
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd import ffi
+    from oracle import search as orc
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20251226)
+    full = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=N, n_code_cols=1)
+    halves = [ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=N // 2) for _ in range(2)]
+    keep_rows, keep_vecs = [], []
+    for r0 in range(0, N, BLOCK):
+        xb = torch.randn((BLOCK, D), generator=gen, device=dev, dtype=torch.float32)
+        codes = (torch.arange(r0, r0 + BLOCK, device=dev, dtype=torch.int64) % 10).to(torch.int32).reshape(-1, 1).contiguous()
+        full.append(xb, codes)
+        halves[r0 // (N // 2)].append(xb)
+        sel = torch.arange(3 - r0 % 10 if r0 % 10 <= 3 else 13 - r0 % 10, BLOCK, 10, device=dev)     # rows with row % 10 == 3
+        keep_rows.append((sel + r0).cpu().numpy())
+        keep_vecs.append(xb[sel].cpu().numpy())
+        torch.cuda.synchronize()
+        del xb
+    assert full.count() == (N, N)
+    sub_rows = np.concatenate(keep_rows)
+    sub = np.concatenate(keep_vecs)
+    assert len(sub_rows) == N // 10 and np.all(sub_rows % 10 == 3)
+
+    rng = np.random.default_rng(7)
+    q = rng.standard_normal((NQ, D)).astype(np.float32)
+    planted = rng.choice(len(sub_rows), 8, replace=False)
+    q[:8] = sub[planted]                                            # stored rows as queries
+    s, r = full.search(q, K)
+    st = full.stats()
+    assert st["fallback_used"] == 0 and st["rows"] == N
+
+    # order / uniqueness
+    assert np.all(r >= 0) and np.all(r < N)
+    assert np.all((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (r[:, :-1] < r[:, 1:])))
+    assert all(len(set(row)) == K for row in r)
+    # planted
+    assert np.array_equal(r[:8, 0], sub_rows[planted]) and np.all(np.abs(s[:8, 0] - 1.0) < 4e-3)
+    # idempotent
+    s2, r2 = full.search(q, K)
+    assert np.array_equal(r, r2) and np.array_equal(s.view(np.uint32), s2.view(np.uint32))
+
+    # shards + merge == full
+    qd = torch.from_numpy(q).to(dev)
+    ps = torch.empty((2, NQ, K), dtype=torch.float32, device=dev)
+    pr = torch.empty((2, NQ, K), dtype=torch.int64, device=dev)
+    for i, h in enumerate(halves):
+        h.search(qd, K, row_base=i * (N // 2), out_scores=ps[i], out_rows=pr[i])
+        h.search_finish()
+    ms = torch.empty((NQ, K), dtype=torch.float32, device=dev)
+    mr = torch.empty((NQ, K), dtype=torch.int64, device=dev)
+    ffi.merge_topk(ps, pr, ms, mr)
+    torch.cuda.synchronize()
+    assert np.array_equal(mr.cpu().numpy(), r) and np.array_equal(ms.cpu().numpy().view(np.uint32), s.view(np.uint32))
+
+    # filter == oracle on the selected 1M rows (8 queries keep the CPU side to a few seconds)
+    fs, fr = full.search(q[8:16], K, filters=[(0, 3)])
+    es, er = orc.cosine_search(sub, q[8:16], K, bf16=True)
+    assert np.array_equal(fr, sub_rows[er]) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
+    # tombstoning the best hit of a query promotes the next one
+    full.tombstone(r[20, :1])
+    s3, r3 = full.search(q[20:21], K)
+    assert np.array_equal(r3[0, : K - 1], r[20, 1:]) and r3[0, K - 1] not in r[20]
+    for h in [full] + halves:
+        h.close()
