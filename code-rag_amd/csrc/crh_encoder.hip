@@ -182,7 +182,8 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r
 //    (With 2 stages and __syncthreads' vmcnt(0) every iteration exposed the whole L2/HBM latency: 600 TFLOP/s.)
 //  * The MFMA is issued as (W-fragment, A-fragment): the accumulator holds C^T tiles -- row = n (registers), col = m (lane)
 //    -- so each lane owns 4 CONSECUTIVE n of one row m and the epilogue stores 8 bytes at a time.
-// DBG (timing ablations only, wrong results): 1 = no LDS-DMA inside the loop, 2 = no MFMA, 3 = no fragment reads in the loop
+// DBG bit mask (timing ablations only, wrong results): 1 = no LDS-DMA inside the loop, 2 = no MFMA, 4 = no fragment reads
+// in the loop, 8 = no DMA of the W tile
 //
 // Persistent: the grid is 8k workgroups (<= one per CU); each walks a strided list of tiles with ONE software pipeline
 // running across tile boundaries -- while a tile's epilogue runs, the first two k-tiles of the next tile are already in
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
     };
     auto stage_one = [&](int i) {
         const int piece = wave * kPer + i;         // pieces 0..31 -> A rows, 32..47 -> W rows
+        if ((DBG & 8) && piece >= BM / 8) return;
         const int r = piece * 8 + prow;            // row inside the stacked [A;W] stage image
         const int c = pslot ^ (r & 7);             // slot s of row r holds chunk s ^ (r & 7)
         const bf16_t *src;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
     auto mfma_group = [&](int nt, const bf16x8 (&fa_)[4], const bf16x8 (&fw_)[4]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            if (DBG == 2) {
+            if (DBG & 2) {
                 asm volatile("" ::"v"(fw_[nt]), "v"(fa_[mt]));
             } else {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw_[nt], fa_[mt], acc[nt][mt], 0, 0, 0);
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             mfma_group(nt, Fa, Wa);
-            if (nt == 0 && DBG != 3) read_frags(buf, 1, Fb, Wb);
+            if (nt == 0 && !(DBG & 4)) read_frags(buf, 1, Fb, Wb);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- middle: stage `it` is fully read; stage it+1 has landed once only what was issued after it remains outstanding
@@ -369,8 +371,8 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             mfma_group(nt, Fb, Wb);
-            if (nt == 0 && have_next && DBG != 3) read_frags(nbuf, 0, Fa, Wa);
-            if (dma && !tile_end && DBG != 1) {   // 6 pieces over the 4 groups: 2, 2, 1, 1
+            if (nt == 0 && have_next && !(DBG & 4)) read_frags(nbuf, 0, Fa, Wa);
+            if (dma && !tile_end && !(DBG & 1)) {   // 6 pieces over the 4 groups: 2, 2, 1, 1
                 stage_one(nt < 2 ? 2 * nt : nt + 2);
                 if (nt < 2) stage_one(2 * nt + 1);
             }
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
         stores_before = (m0 + BM <= M) ? 8 : 0;   // a ragged tile may have skipped stores: assume none are in flight
         if (dma) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image has been read back before its stage is refilled
-            if (DBG != 1) {
+            if (!(DBG & 1)) {
 #pragma unroll
                 for (int i = 0; i < kPer; ++i) stage_one(i);
             }
@@ -707,7 +709,10 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
     case 0: CRH_DBG_LAUNCH(0); break;
     case 1: CRH_DBG_LAUNCH(1); break;
     case 2: CRH_DBG_LAUNCH(2); break;
-    case 3: CRH_DBG_LAUNCH(3); break;
+    case 4: CRH_DBG_LAUNCH(4); break;
+    case 5: CRH_DBG_LAUNCH(5); break;
+    case 6: CRH_DBG_LAUNCH(6); break;
+    case 8: CRH_DBG_LAUNCH(8); break;
     default: return fail(CRH_E_INVALID, "debug gemm: variant %d", variant);
     }
 #undef CRH_DBG_LAUNCH

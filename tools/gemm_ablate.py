@@ -13,9 +13,10 @@ for (T, N, K) in ((32768, 2304, 768), (32768, 768, 3072)):
     w = (torch.randn((N, K), device=dev) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn((N,), device=dev)
     y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
-    res = {v: [] for v in range(4)}
+    VARS = (0, 1, 5, 2, 6, 8)
+    res = {v: [] for v in VARS}
     for rnd in range(6):
-        for v in range(4):
+        for v in VARS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
@@ -25,7 +26,8 @@ for (T, N, K) in ((32768, 2304, 768), (32768, 768, 3072)):
             if rnd:
                 res[v].append(e0.elapsed_time(e1) / 5 * 1e3)
     fl = 2.0 * T * N * K
-    names = {0: "full", 1: "no DMA in loop", 2: "no MFMA", 3: "no fragment reads"}
-    for v in range(4):
+    names = {0: "full", 1: "no DMA in loop", 2: "no MFMA", 4: "no fragment reads", 5: "MFMA only (no DMA, no frag reads)",
+             6: "DMA only (no MFMA, no frag reads)", 8: "no W DMA"}
+    for v in VARS:
         us = sorted(res[v])[len(res[v]) // 2]
-        print(f"T={T} N={N} K={K} {names[v]:18s} median {us:8.1f} us  ({fl / us / 1e6:7.1f} TFLOP/s-equivalent)")
+        print(f"T={T} N={N} K={K} {names[v]:34s} median {us:8.1f} us  ({fl / us / 1e6:7.1f} TFLOP/s-equivalent)")
