@@ -277,6 +277,20 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q
 
 // ------------------------------------------------------------------ the scan
 
+// Streaming load of one 1-KiB corpus piece with the `nt` cache policy.  __builtin_nontemporal_load keeps the flag on only a
+// fraction of the unrolled loads (those that get an immediate offset lose it), so the instruction is written out; the
+// compiler does not know an asm load is asynchronous, hence nt_wait(): a counted vmcnt that takes the destination as an
+// in/out operand, which makes every consumer (the MFMA) depend on the wait.
+__device__ __forceinline__ void nt_load(u32x4 &dst, const u32x4 *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void nt_wait(u32x4 &dst)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(N));
+}
+
 // MODE 0 (seed):  items are sample tiles; writes gmax[item][q] = max over the tile's valid rows.
 // MODE 1 (main):  items are all tiles; rows with score >= tau[q] become candidates.
 //
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     u32x4 ring[RING];
     if (i < nitems) {
 #pragma unroll
-        for (int d = 0; d < RING; ++d) ring[d] = __builtin_nontemporal_load(xp + d * 64);
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
     }
     while (i < nitems) {
         const int inext = i + total;
@@ -340,12 +354,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
             const int s1 = (s + 1 < KSTEPS) ? s + 1 : s;
             const u32x4 nb0 = qs[s1 * 64 + lane];
             const u32x4 nb1 = qs[((QB - 1) * KSTEPS + s1) * 64 + lane];
+            nt_wait<RING - 1>(ring[s % RING]);   // the oldest of the RING loads in flight has landed (issue order)
             const bf16x8 xa = __builtin_bit_cast(bf16x8, ring[s % RING]);
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
             if (QB == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
             const int sp = s + RING;
-            ring[s % RING] = (sp < KSTEPS) ? __builtin_nontemporal_load(xp + sp * 64)
-                                           : __builtin_nontemporal_load(xn + (sp - KSTEPS) * 64);
+            const u32x4 *src = (sp < KSTEPS) ? xp + sp * 64 : xn + (sp - KSTEPS) * 64;
+            nt_load(ring[s % RING], src);
             b0 = nb0;
             b1 = nb1;
             __builtin_amdgcn_sched_barrier(0);
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
         xp = xn;
         i = inext;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the last tile are still in flight
 
     if (MODE == 1) {
         // Hand the workgroup's candidates over to the per-query lists: count per query in LDS, reserve
