@@ -60,7 +60,6 @@ struct crh_index {
     float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
     u32x4 *qfrag = nullptr, *wave_lists = nullptr;
     uint32_t *effmask = nullptr;
-    unsigned int *qcount = nullptr;
     u32x2 *qlist = nullptr;
     unsigned long long *skeys = nullptr;
     SearchStatus *status = nullptr;
@@ -136,7 +135,6 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
         CRH_TRY(dev_alloc(&h->qn, (int64_t)kMaxQ * h->dim));
         CRH_TRY(dev_alloc(&h->qfrag, (int64_t)2 * h->ksteps * 64));
         CRH_TRY(dev_alloc(&h->tau, kMaxQ));
-        CRH_TRY(dev_alloc(&h->qcount, kMaxQ));
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
         CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
     }
@@ -208,7 +206,7 @@ int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, 
 {
 #define CRH_SCAN(KS, QB)                                                                                                       \
     hipLaunchKernelGGL((k_scan<KS, MODE, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, h->qfrag, h->tau, \
-                       mask, nitems, stride, h->gmax, h->wave_lists, wave_cap, h->qcount, h->qlist, qcap, stt)
+                       mask, nitems, stride, h->gmax, h->wave_lists, wave_cap, stt->qcount, h->qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_SCAN(24, 2); break;
     case 48: CRH_SCAN(48, 2); break;
@@ -236,7 +234,6 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     const int wave_cap = h->ws_wave_cap, qcap = h->ws_qcap;
     const float margin = margin_for(h);
     SearchStatus *stt = h->status + slot;
-    CRH_HIP(hipMemsetAsync(h->qcount, 0, kMaxQ * sizeof(unsigned int), st));
 
     if (h->dtype == CRH_DTYPE_BF16)
         hipLaunchKernelGGL(k_prep_queries<true>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
@@ -253,10 +250,10 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
-        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, h->qcount, qcap, h->skeys, h->qn, h->xt,
+        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, stt->qcount, qcap, h->skeys, h->qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     else
-        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, h->qlist, h->qcount, qcap, h->skeys, h->qn, h->xt,
+        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, h->qlist, stt->qcount, qcap, h->skeys, h->qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     CRH_HIP(hipGetLastError());
     h->stats.rows += h->count;
@@ -404,7 +401,6 @@ int crh_index_destroy(crh_index *h)
     dev_free(h->qfrag);
     dev_free(h->wave_lists);
     dev_free(h->effmask);
-    dev_free(h->qcount);
     dev_free(h->qlist);
     dev_free(h->skeys);
     dev_free(h->status);

@@ -36,6 +36,7 @@ struct SearchStatus {
     unsigned int q_overflow;
     unsigned long long candidates;
     unsigned long long pad_;
+    unsigned int qcount[kMaxQ];  // per-query candidate counters of the batch (zeroed with the rest by ONE memset)
 };
 
 // ------------------------------------------------------------------ small helpers
