@@ -252,3 +252,40 @@ def test_other_embedding_dimensions(gpu, dim, bf16):
     idx.close()
     with pytest.raises(ffi.NativeError):
         ffi.Index(100, ffi.DTYPE_F32, 64)
+
+
+def test_c_abi_error_paths(gpu):
+    """Every misuse comes back as a negative status with a message -- no crash, no exception across the ABI."""
+    import ctypes as C
+    ffi = _ffi()
+    L = ffi.lib()
+    h = C.c_void_p()
+    assert L.crh_index_create(768, 7, 100, 0, 0, C.byref(h)) == ffi.E_INVALID and b"dtype" in L.crh_last_error()
+    assert L.crh_index_create(768, 0, 0, 0, 0, C.byref(h)) == ffi.E_INVALID
+    assert L.crh_index_create(768, 0, 100, 0, 99, C.byref(h)) == ffi.E_INVALID and b"device" in L.crh_last_error()
+    assert L.crh_index_count(None, None, None) == ffi.E_INVALID
+    idx = ffi.Index(768, ffi.DTYPE_F32, capacity_rows=256, n_code_cols=1)
+    x = _corpus(100, 30)
+    with pytest.raises(ffi.NativeError, match="code columns"):
+        idx.append(x)                                                   # codes missing
+    idx.append(x, np.zeros((100, 1), np.int32))
+    q = _corpus(2, 31)
+    for bad_k in (0, -3, ffi.MAX_K + 1):
+        with pytest.raises(ffi.NativeError) as e:
+            idx.search(q, bad_k)
+        assert e.value.code in (ffi.E_CAPACITY, ffi.E_INVALID)
+    with pytest.raises(ffi.NativeError, match="filter column"):
+        idx.search(q, 5, filters=[(3, 0)])
+    with pytest.raises(ffi.NativeError):
+        idx.search(q, 5, filters=[(0, 0)] * 9)                          # more than CRH_MAX_FILTERS
+    with pytest.raises(ffi.NativeError):
+        idx.search(np.zeros((1, 100), np.float32), 5)                   # wrong query width
+    idx.tombstone(np.asarray([-5, 10_000, 3]))                          # out-of-range rows are ignored
+    assert idx.count() == (100, 99)
+    with pytest.raises(ffi.NativeError):
+        idx.read_rows(50, 100)
+    s, r = idx.search(q, ffi.MAX_K)                                     # k far above the row count: padded
+    assert (r[:, :99] >= 0).all() and (r[:, 99:] == -1).all() and 3 not in r[0]
+    idx.close()
+    with pytest.raises(ffi.NativeError, match="closed"):
+        idx.count()
