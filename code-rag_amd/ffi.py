@@ -241,6 +241,8 @@ class Index:
         if nq and int(queries.shape[1]) != self.dim:
             raise NativeError(E_INVALID, f"query dim {queries.shape[1]} != index dim {self.dim}")
         farr, nf = _filters(filters)
+        if not 0 < k <= MAX_K:
+            raise NativeError(E_CAPACITY, f"k={k} outside 1..{MAX_K}")
         if out_scores is None:
             out_scores = np.empty((nq, k), dtype=np.float32)
             out_rows = np.empty((nq, k), dtype=np.int64)
