@@ -50,6 +50,8 @@ def main() -> None:
     ap.add_argument("--seed-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--embed-chunks", type=int, default=20000, help="synthetic chunks for the encoder leg (0 = skip; BASELINE C2 uses 100000)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --rows per GPU (BASELINE C4a); strong: --rows in total, split over the ranks (C4b)")
     ap.add_argument("--check-rows", type=int, default=200_000, help="rows of the parity subsample checked vs the oracle")
     args = ap.parse_args()
 
@@ -72,6 +74,8 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     D, N, B, K = 768, args.rows, args.queries, args.k
+    if args.scaling == "strong":
+        N = (args.rows + world - 1) // world
     dtype = ffi.DTYPE_BF16 if args.dtype == "bf16" else ffi.DTYPE_F32
     elem = 2  # the scan always streams the bf16 tiled copy
     stream = torch.cuda.current_stream().cuda_stream
@@ -106,13 +110,21 @@ def main() -> None:
         mer_s = torch.empty((B, K), dtype=torch.float32, device=dev)
         mer_r = torch.empty((B, K), dtype=torch.int64, device=dev)
 
-    def step(i: int) -> None:
+    # per-step device time stamps on the launch stream (torch's current stream): step i spans ev[i] .. ev[i+1]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev_x = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if world > 1 else None
+
+    def step(i: int, timed: bool = False) -> None:
         s, r = out_s[i % nslots], out_r[i % nslots]
         idx.search(qd, K, row_base=row_base, out_scores=s, out_rows=r, stream=stream)
         if world > 1:
+            if timed:
+                ev_x[i].record()
             dist.all_gather_into_tensor(gat_s.view(world * B, K), s)
             dist.all_gather_into_tensor(gat_r.view(world * B, K), r)
             ffi.merge_topk(gat_s, gat_r, mer_s, mer_r, stream)
+        if timed:
+            ev[i + 1].record()
 
     def fence() -> None:
         if world > 1:
@@ -125,12 +137,15 @@ def main() -> None:
     fence()
     idx.set_profiling(True)
     t0 = time.perf_counter()
+    ev[0].record()
     for i in range(args.steps):
-        step(i)
+        step(i, True)
     idx.search_finish(stream)  # also verifies no candidate buffer overflowed in any timed step
     fence()
     dt = time.perf_counter() - t0
     log(f"search timed: {args.steps} steps in {dt:.3f} s")
+    per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
+    exchange = np.array([ev_x[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]) if world > 1 else None
     scan_ms_total, scan_launches = idx.profile()
     idx.set_profiling(False)
     stats = idx.stats()
@@ -175,17 +190,23 @@ def main() -> None:
         "value": value,
         "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "bf16 corpus/query, f32 accumulate" if args.dtype == "bf16" else "f32 store (bf16 scan + f32 canonical re-score)",
         "data": "synthetic: N(0,I) rows generated on device (torch seed 20251226+rank), normalised on insert; queries numpy default_rng(7)",
         "config": {"workload": f"{world}x MI355X: {N}x{D} {args.dtype} corpus per GPU resident in HBM, batch-{B} queries, exact top-{K}"
-                               + (", all-gather + merge of per-GPU top-k over RCCL" if world > 1 else ""),
+                               + (", all-gather + merge of per-GPU top-k over RCCL" if world > 1 else "")
+                               + (f" ({args.rows} rows in total, strong scaling)" if args.scaling == "strong" else ""),
                    "rows_per_gpu": N, "dim": D, "batch": B, "k": K, "parallelism": f"row-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None,
                      "kernel": "k_scan<48,1,16,8>", "kernel_ms": scan_ms, "launches": scan_launches,
                      "algorithmic_bytes_per_launch": alg_bytes},
+        "step_ms_device": {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
+                           "p90": float(np.percentile(per_step, 90))},
+        "exchange_ms_device": ({"median": float(np.median(exchange)), "p10": float(np.percentile(exchange, 10)),
+                                "p90": float(np.percentile(exchange, 90)),
+                                "what": "2 RCCL all-gathers of [B,k] + k_merge_topk, rank 0"} if exchange is not None else None),
         "search_stats": stats,
         "parity": parity,
     }

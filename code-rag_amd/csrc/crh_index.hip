@@ -244,7 +244,7 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
-    hipLaunchKernelGGL(k_tau, dim3(h->batch_q), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, h->tau);
+    hipLaunchKernelGGL(k_tau, dim3(h->batch_q), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
     CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));

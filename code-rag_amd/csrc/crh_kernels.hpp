@@ -575,9 +575,9 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
 // ------------------------------------------------------------------ threshold from the seed sample
 
 // tau[q] = (k-th largest of the G sampled tile maxima of query q) - margin; -inf if G < k or fewer than k
-// sampled tiles hold a valid row.  Any k tiles each contribute >= 1 row at or above their maximum, so
+// sampled tiles hold a valid row; +inf for the padding columns q >= nq of a short batch (they nominate nothing).  Any k tiles each contribute >= 1 row at or above their maximum, so
 // at least k valid rows score >= the k-th largest maximum: it is a lower bound of the true k-th score.
-__global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int G, int k, float margin,
+__global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int G, int k, float margin, int nq,
                                              float *__restrict__ tau)
 {
     extern __shared__ uint32_t col[];  // [G] ordered keys of this query's tile maxima
@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
     __shared__ unsigned int bcast[2];
     const int q = blockIdx.x;
     float t = -INFINITY;
-    if (G >= k) {
+    if (q >= nq) {   // block-uniform
+        t = INFINITY;
+    } else if (G >= k) {
         for (int i = threadIdx.x; i < G; i += 256) col[i] = ord_f32(gmax[(size_t)i * 64 + q]);
         __syncthreads();
         const uint32_t key = wg_kth_largest<uint32_t, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k, hist, bcast);

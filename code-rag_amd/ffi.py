@@ -162,6 +162,34 @@ def _is_dev(x) -> int:
     return int(not isinstance(x, np.ndarray) and getattr(x, "is_cuda", False))
 
 
+_NP_NAMES = {"float32": np.float32, "int32": np.int32, "int64": np.int64}
+
+
+def _typed(x, want: str, what: str):
+    """The C side sees a bare pointer: refuse anything whose element type or layout it would misread.
+    numpy inputs are converted (a copy is fine on the host); device tensors must already be right."""
+    if x is None or isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=_NP_NAMES[want])
+    if str(x.dtype).rsplit(".", 1)[-1] != want:
+        raise NativeError(E_INVALID, f"{what} must be {want}, got {x.dtype}")
+    if not x.is_contiguous():
+        raise NativeError(E_INVALID, f"{what} must be contiguous")
+    return x
+
+
+def _out(x, want: str, what: str, shape):
+    if isinstance(x, np.ndarray):
+        if x.dtype != _NP_NAMES[want] or not x.flags.c_contiguous:
+            raise NativeError(E_INVALID, f"{what} must be a C-contiguous {want} array")
+    else:
+        _typed(x, want, what)
+    if tuple(x.shape) != tuple(shape):
+        raise NativeError(E_INVALID, f"{what} has shape {tuple(x.shape)}, expected {tuple(shape)}")
+    return x
+
+
 class Index:
     """Owning wrapper of one ``crh_index`` handle (one collection shard on one GPU)."""
 
@@ -174,8 +202,8 @@ class Index:
         self.capacity_rows = (capacity_rows + 31) // 32 * 32
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            lib().crh_index_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:   # (module globals are gone at interpreter shutdown)
+            _lib.crh_index_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -192,10 +220,8 @@ class Index:
     def append(self, vecs, codes=None, stream: int = 0, preprocessed: bool = False) -> int:
         """vecs: float32 [n, dim] numpy array (host) or CUDA torch tensor.  Returns the first new row.
         ``preprocessed=True`` stores the rows verbatim (restoring a snapshot made with :meth:`read_rows`)."""
-        if isinstance(vecs, np.ndarray):
-            vecs = np.ascontiguousarray(vecs, dtype=np.float32)
-            if codes is not None:
-                codes = np.ascontiguousarray(codes, dtype=np.int32)
+        vecs = _typed(vecs, "float32", "vecs")
+        codes = _typed(codes, "int32", "codes")
         n = int(vecs.shape[0])
         if n and int(vecs.shape[1]) != self.dim:
             raise NativeError(E_INVALID, f"vector dim {vecs.shape[1]} != index dim {self.dim}")
@@ -233,10 +259,9 @@ class Index:
                stream: int = 0):
         """queries: [nq, dim] float32 numpy (host) or CUDA tensor.  With ``out_*`` CUDA tensors the call is
         asynchronous (finish with :meth:`search_finish`); otherwise numpy results are returned."""
-        if isinstance(queries, np.ndarray):
-            queries = np.ascontiguousarray(queries, dtype=np.float32)
-            if queries.ndim == 1:
-                queries = queries[None, :]
+        queries = _typed(queries, "float32", "queries")
+        if queries.ndim == 1:
+            queries = queries[None, :]
         nq = int(queries.shape[0])
         if nq and int(queries.shape[1]) != self.dim:
             raise NativeError(E_INVALID, f"query dim {queries.shape[1]} != index dim {self.dim}")
@@ -246,6 +271,11 @@ class Index:
         if out_scores is None:
             out_scores = np.empty((nq, k), dtype=np.float32)
             out_rows = np.empty((nq, k), dtype=np.int64)
+        else:
+            _out(out_scores, "float32", "out_scores", (nq, k))
+            _out(out_rows, "int64", "out_rows", (nq, k))
+            if _is_dev(out_scores) != _is_dev(out_rows):
+                raise NativeError(E_INVALID, "out_scores and out_rows must live in the same memory space")
         check(lib().crh_search(self._handle(), nq, _ptr(queries), _is_dev(queries), k, farr, nf, row_base,
                                _ptr(out_scores), _ptr(out_rows), _is_dev(out_scores), stream))
         return out_scores, out_rows
@@ -278,4 +308,8 @@ class Index:
 def merge_topk(scores, rows, out_scores, out_rows, stream: int = 0) -> None:
     """scores/rows: CUDA tensors [nlists, nq, k] (f32 / i64); out_*: [nq, k]."""
     nl, nq, k = (int(v) for v in scores.shape)
+    _typed(scores, "float32", "scores")
+    _out(rows, "int64", "rows", (nl, nq, k))
+    _out(out_scores, "float32", "out_scores", (nq, k))
+    _out(out_rows, "int64", "out_rows", (nq, k))
     check(lib().crh_merge_topk(nl, nq, k, _ptr(scores), _ptr(rows), _ptr(out_scores), _ptr(out_rows), stream))

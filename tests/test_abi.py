@@ -49,3 +49,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f"{f} reaches into oracle/"
+
+
+def test_binding_refuses_pointers_the_c_side_would_misread():
+    """The ABI takes bare pointers, so the binding is where a float64 / strided / mis-shaped device tensor has to stop
+    (a float64 query tensor once went through as garbage float32 pairs)."""
+    import numpy as np
+    import torch
+    from coderag_amd import ffi
+    good = torch.zeros((4, 8), dtype=torch.float32)
+    assert ffi._typed(good, "float32", "queries") is good
+    with pytest.raises(ffi.NativeError, match="float32"):
+        ffi._typed(good.double(), "float32", "queries")
+    with pytest.raises(ffi.NativeError, match="contiguous"):
+        ffi._typed(good.t(), "float32", "queries")
+    assert ffi._typed(np.zeros((2, 3)), "float32", "vecs").dtype == np.float32     # host arrays are converted
+    with pytest.raises(ffi.NativeError, match="shape"):
+        ffi._out(torch.zeros((4, 7), dtype=torch.int64), "int64", "out_rows", (4, 8))
+    with pytest.raises(ffi.NativeError, match="int64"):
+        ffi._out(np.zeros((4, 8), np.int32), "int64", "out_rows", (4, 8))

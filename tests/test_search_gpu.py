@@ -280,6 +280,9 @@ def test_c_abi_error_paths(gpu):
         idx.search(q, 5, filters=[(0, 0)] * 9)                          # more than CRH_MAX_FILTERS
     with pytest.raises(ffi.NativeError):
         idx.search(np.zeros((1, 100), np.float32), 5)                   # wrong query width
+    import torch
+    with pytest.raises(ffi.NativeError, match="float32"):
+        idx.search(torch.zeros((2, 768), dtype=torch.float64, device="cuda"), 5)   # would be read as float32 pairs
     idx.tombstone(np.asarray([-5, 10_000, 3]))                          # out-of-range rows are ignored
     assert idx.count() == (100, 99)
     with pytest.raises(ffi.NativeError):
@@ -289,3 +292,22 @@ def test_c_abi_error_paths(gpu):
     idx.close()
     with pytest.raises(ffi.NativeError, match="closed"):
         idx.count()
+
+
+def test_short_batches_do_not_nominate_for_padding_columns(gpu):
+    """A batch of fewer than 64 queries pads the MFMA columns with zero vectors; those columns must nominate nothing
+    (they once passed every row, which overflowed the candidate buffers and quadrupled the scan time)."""
+    ffi = _ffi()
+    n = 200_000
+    x = _corpus(n, 40)
+    idx = ffi.Index(768, ffi.DTYPE_BF16, capacity_rows=n)
+    idx.append(x)
+    q = _corpus(64, 41)
+    full_s, full_r = idx.search(q, 10)
+    full = idx.stats()
+    for nq in (1, 3, 33):
+        s, r = idx.search(q[:nq], 10)
+        st = idx.stats()
+        assert np.array_equal(r, full_r[:nq]) and np.array_equal(s.view(np.uint32), full_s[:nq].view(np.uint32))
+        assert st["fallback_used"] == 0
+        assert st["candidates"] <= full["candidates"]
