@@ -37,7 +37,15 @@ __device__ __forceinline__ unsigned int f2bf(float x)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u | 0x00400000u) >> 16;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+// two floats -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (the integer sequence of f2bf is
+// ~8 VALU instructions per element; a GEMM epilogue converts 512 elements per lane and spent ~10 us per tile on it)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned int pack2(float a, float b)
+{
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 
 // erf-GELU, x * Phi(x), with Phi from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16's 2^-9): one v_exp, one
 // v_rcp and a degree-5 Horner chain instead of libm's branchy erff (the FFN1 epilogue evaluates 64 of these per lane
@@ -633,6 +641,8 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
     sent[(size_t)b * D + d] = acc / (float)cnt;  // an all-pad row divides 0/0 exactly like the reference's mean
 }
 
+#include "crh_gemm256.hpp"
+
 }  // namespace enc
 }  // namespace crh
 
@@ -659,6 +669,60 @@ unsigned gemm_grid(int T, int N)
     return (unsigned)(crh::ceil_div(want, 8) * 8);
 }
 
+// The 256x256 ping-pong kernel (crh_gemm256.hpp) takes over when its shape constraints hold and there are enough tiles
+// to give every CU at least one; CODERAG_HIP_GEMM256=0 keeps everything on k_gemm_nt, =2 forces it whenever the shape allows.
+int gemm256_mode()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("CODERAG_HIP_GEMM256");
+        mode = e ? atoi(e) : 1;
+    }
+    return mode;
+}
+bool use_gemm256(int T, int N, int K)
+{
+    if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || gemm256_mode() == 0) return false;
+    if ((int64_t)T * K * 2 >= (1LL << 32) || (int64_t)N * K * 2 >= (1LL << 32)) return false;   // its cursor uses 32-bit byte offsets
+    const int64_t tiles = crh::ceil_div(T, g256::BM) * (N / g256::BN);
+    return gemm256_mode() == 2 || tiles >= 256;
+}
+unsigned gemm256_grid(int T, int N)
+{
+    int cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (!cached) {
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+            cus = prop.multiProcessorCount;
+        cached = cus;
+    }
+    const int64_t tiles = crh::ceil_div(T, g256::BM) * (N / g256::BN);
+    const int64_t want = std::min<int64_t>(tiles, (cached / 8) * 8);
+    return (unsigned)(crh::ceil_div(want, 8) * 8);
+}
+int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        attr = true;
+    }
+    const dim3 grid(gemm256_grid(T, N)), block(g256::WAVES * 64);
+    const bf16_t *xa = (const bf16_t *)x, *wa = (const bf16_t *)w, *ra = (const bf16_t *)res;
+    bf16_t *ya = (bf16_t *)y;
+    if (epi == 0)
+        hipLaunchKernelGGL((g256::k_gemm_pp<0>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
+    else if (epi == 1)
+        hipLaunchKernelGGL((g256::k_gemm_pp<1>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
+    else
+        hipLaunchKernelGGL((g256::k_gemm_pp<2>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 constexpr size_t kGemmLds = (size_t)STAGES * (BM + BN) * BK * 2;  // 144 KB of the CU's 160 KB
 
 int gemm_lds_attr()
@@ -681,8 +745,9 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
     if (!x || !w || !bias || !y) return fail(CRH_E_INVALID, "gemm: NULL pointer");
     if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
     if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm: act=%d (0 none, 1 gelu)", act);
-    const dim3 grid(gemm_grid(T, N));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_gemm256(T, N, K)) return launch_gemm256(act, x, w, bias, nullptr, y, T, N, K, st);
+    const dim3 grid(gemm_grid(T, N));
     CRH_TRY(gemm_lds_attr());
     if (act == 1)
         hipLaunchKernelGGL((k_gemm_nt<1, 0>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
@@ -706,6 +771,24 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
                            (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);                                                 \
     } while (0)
     switch (variant) {
+    case 16:   // the 256x256 ping-pong kernel regardless of the tile count (results are valid)
+        if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32))
+            return fail(CRH_E_INVALID, "debug gemm: variant 16 needs N%%256==0, K%%128==0, K>=256, T*K*2 < 4 GiB");
+        return launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st);
+    case 17:
+    case 18: {   // ablations of the ping-pong kernel's epilogue: 17 = no global stores, 18 = no epilogue
+        if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
+        const dim3 grid256(gemm256_grid(T, N)), block(g256::WAVES * 64);
+        if (variant == 17) {
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+            hipLaunchKernelGGL((g256::k_gemm_pp<0, 1>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        } else {
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+            hipLaunchKernelGGL((g256::k_gemm_pp<0, 2>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        }
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     case 0: CRH_DBG_LAUNCH(0); break;
     case 1: CRH_DBG_LAUNCH(1); break;
     case 2: CRH_DBG_LAUNCH(2); break;
@@ -727,6 +810,12 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
     if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_gemm256(T, N, K)) {
+        CRH_TRY(launch_gemm256(2, x, w, bias, residual, y, T, N, K, st));
+        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     CRH_TRY(gemm_lds_attr());
     hipLaunchKernelGGL((k_gemm_nt<2, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
                        (const bf16_t *)residual, (bf16_t *)y, T, N, K);

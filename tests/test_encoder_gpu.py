@@ -41,7 +41,50 @@ def test_gemm_bias_act(gpu, T, N, K, act):
     _close(torch, y, ref, rel=2 ** -7, abs_=2e-3)           # one bf16 rounding of the result + f32 accumulation order
 
 
-@pytest.mark.parametrize("T,K", [(256, 768), (100, 3072), (6000, 768)])
+# The 256x256 ping-pong kernel (crh_gemm256.hpp) takes over from 256 tiles up: large T through the public entry, and
+# small / ragged / single-tile shapes through the debug entry (variant 16 runs it regardless of the tile count).
+@pytest.mark.parametrize("T,N,K,act", [(22000, 768, 768, 0), (8192, 3072, 768, 1), (7400, 2304, 768, 0), (21931, 768, 3072, 0)])
+def test_gemm256_through_public_entry(gpu, T, N, K, act):
+    test_gemm_bias_act(gpu, T, N, K, act)
+
+
+@pytest.mark.parametrize("T,N,K", [(256, 256, 256), (1, 256, 256), (300, 768, 768), (777, 2304, 384), (4096, 768, 3072), (5121, 3072, 768)])
+def test_gemm256_small_and_ragged(gpu, T, N, K):
+    torch, ffi, dev = _env()
+    g = torch.Generator(device="cpu").manual_seed(T * 7 + N)
+    a = torch.randn((T, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((N,), generator=g).to(dev)
+    y = torch.full((T + 8, N), 7.0, dtype=torch.bfloat16, device=dev)     # 8 guard rows: nothing may be written past T
+    ffi.check(ffi.lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, 16, 0))
+    ref = a.float() @ w.float().T + b
+    torch.cuda.synchronize()
+    _close(torch, y[:T], ref, rel=2 ** -7, abs_=2e-3)
+    assert bool((y[T:] == 7.0).all())
+
+
+def test_gemm256_repeatable(gpu):
+    """The schedule is ordered by counted waits and barrier ticks, not by luck: 20 runs of a many-tile shape are
+    bit-identical to the first (a read that raced its LDS-DMA would show up as an occasional differing tile)."""
+    torch, ffi, dev = _env()
+    T, N, K = 24576, 768, 3072
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn((T, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((N,), generator=g).to(dev)
+    outs = []
+    for _ in range(20):
+        y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
+        ffi.check(ffi.lib().crh_gemm_bf16_bias(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, 0, 0))
+        outs.append(y)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T + b
+    _close(torch, outs[0], ref, rel=2 ** -7, abs_=2e-3)
+    for y in outs[1:]:
+        assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
+
+
+@pytest.mark.parametrize("T,K", [(256, 768), (100, 3072), (6000, 768), (22100, 3072), (23040, 768)])
 def test_gemm_residual_layernorm(gpu, T, K):
     torch, ffi, dev = _env()
     g = torch.Generator(device="cpu").manual_seed(K)
