@@ -310,10 +310,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
                     float v0 = acc[nt][mt][0] + bv[nt].x, v1 = acc[nt][mt][1] + bv[nt].y, v2 = acc[nt][mt][2] + bv[nt].z,
                           v3 = acc[nt][mt][3] + bv[nt].w;
                     if (EPI == 1) {
-                        v0 = gelu_erf(v0);
-                        v1 = gelu_erf(v1);
-                        v2 = gelu_erf(v2);
-                        v3 = gelu_erf(v3);
+                        const f32x2_t ga = gelu_erf2(f32x2_t{v0, v1}), gb = gelu_erf2(f32x2_t{v2, v3});
+                        v0 = ga.x;
+                        v1 = ga.y;
+                        v2 = gb.x;
+                        v3 = gb.y;
                     }
                     if (EPI == 2) {
                         const u32x2 r2 = rv[mt >> 2][nt][mt & 3];

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the encoder GEMM shapes: the 256x128 3-stage kernel (debug variant 0) against the 256x256 ping-pong kernel
+"""(variants 100 / 101 = the public entry crh_gemm_bf16_bias with act 0 / 1)
+Times the encoder GEMM shapes: the 256x128 3-stage kernel (debug variant 0) against the 256x256 ping-pong kernel
 (variant 16), interleaved rounds in one process, random data.  python tools/gemm_bench.py [T]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,12 +21,17 @@ for name, N, K in shapes:
     res = {}
     for rnd in range(5):
         for v in VARIANTS:
+            def call():
+                if v >= 100:
+                    ffi.check(L.crh_gemm_bf16_bias(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v - 100, 0))
+                else:
+                    ffi.check(L.crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v, 0))
             for _ in range(3):
-                ffi.check(L.crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v, 0))
+                call()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                ffi.check(L.crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v, 0))
+                call()
             e1.record()
             torch.cuda.synchronize()
             res.setdefault(v, []).append(e0.elapsed_time(e1) / 20 * 1e3)
