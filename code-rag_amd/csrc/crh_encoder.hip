@@ -550,45 +550,65 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
                 }
             }
             // s[qi][t][r] = <K[kt*64 + 16t + 4g + r], Q[q0(qi) + c16]>
+            // Softmax of the tile on the VALU, which is what bounds this kernel (16 scores per lane, tile and query tile):
+            // the running maximum is kept on the RAW scores and the 1/sqrt(d)*log2(e) scale is folded into the exponent's fma;
+            // the per-key validity select runs only on a tile that has a masked key (normally just a row's last tile);
+            // fma / sum / rescale go through the packed-f32 pipe two elements at a time, exp2 is the bare v_exp_f32.
+            const bool full = vm == ~0ull;               // wave-uniform
+            const f32x2_t sc2 = {scale_log2, scale_log2};
             bf16x8 pb[QT][2];
 #pragma unroll
             for (int qi = 0; qi < QT; ++qi) {
                 float mloc = -INFINITY;
+                if (full) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = (vm >> (16 * t + 4 * g + r)) & 1ull;
-                        const float v = ok ? s[qi][t][r] * scale_log2 : -INFINITY;
-                        s[qi][t][r] = v;
-                        mloc = fmaxf(mloc, v);
+                    for (int t = 0; t < 4; ++t) {
+                        mloc = fmaxf(fmaxf(mloc, s[qi][t][0]), s[qi][t][1]);
+                        mloc = fmaxf(fmaxf(mloc, s[qi][t][2]), s[qi][t][3]);
                     }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool ok = (vm >> (16 * t + 4 * g + r)) & 1ull;
+                            const float v = ok ? s[qi][t][r] : -INFINITY;
+                            s[qi][t][r] = v;
+                            mloc = fmaxf(mloc, v);
+                        }
+                }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                const float mnew = fmaxf(mrun[qi], mloc);  // finite: vm != 0 guarantees a valid key in this tile
-                const float alpha = exp2f(mrun[qi] - mnew);
-                float psum = 0.f;
+                const float mnew = fmaxf(mrun[qi], mloc);  // raw-score maximum; finite: vm != 0 guarantees a valid key in this tile
+                const float alpha = __builtin_amdgcn_exp2f((mrun[qi] - mnew) * scale_log2);   // first tile: 2^-inf = 0
+                const float nb = -mnew * scale_log2;
+                const f32x2_t nb2 = {nb, nb};
+                f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    float p[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        p[j] = exp2f(s[qi][2 * s2 + (j >> 2)][j & 3] - mnew);
-                        psum += p[j];
-                    }
                     u32x4 pk;
-                    pk.x = pack2(p[0], p[1]);
-                    pk.y = pack2(p[2], p[3]);
-                    pk.z = pack2(p[4], p[5]);
-                    pk.w = pack2(p[6], p[7]);
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {         // elements 2*j2, 2*j2+1 of this half: accumulator t = 2*s2 + (j2 >> 1)
+                        const f32x4 sv = s[qi][2 * s2 + (j2 >> 1)];
+                        const f32x2_t raw = (j2 & 1) ? f32x2_t{sv[2], sv[3]} : f32x2_t{sv[0], sv[1]};
+                        const f32x2_t e = __builtin_elementwise_fma(raw, sc2, nb2);   // masked: -inf * scale + nb = -inf -> p = 0
+                        const f32x2_t pj = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                        ps2 += pj;
+                        pk[j2] = pack2(pj.x, pj.y);
+                    }
                     pb[qi][s2] = __builtin_bit_cast(bf16x8, pk);
                 }
+                float psum = ps2.x + ps2.y;
                 psum += __shfl_xor(psum, 16);
                 psum += __shfl_xor(psum, 32);
                 lrun[qi] = lrun[qi] * alpha + psum;
                 mrun[qi] = mnew;
+                const f32x2_t al2 = {alpha, alpha};
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) oacc[qi][dt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f32x2_t lo = f32x2_t{oacc[qi][dt][0], oacc[qi][dt][1]} * al2, hi = f32x2_t{oacc[qi][dt][2], oacc[qi][dt][3]} * al2;
+                    oacc[qi][dt] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                }
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -841,16 +861,35 @@ int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B
     const float scale_log2 = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
     const size_t lds = (size_t)((L + 63) & ~63) * 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (L > 192) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_attn<8, 4>), dim3(H, B), dim3(512), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
-    } else {
-        hipLaunchKernelGGL((k_attn<4, 1>), dim3(H, B), dim3(256), lds, st, (const bf16_t *)qkv, (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);
+    // One 16-row query tile per wave at a time (101 VGPRs: 4-5 waves per SIMD) and as many waves per CU as the K/V images
+    // allow: up to 320 tokens two 8-wave workgroups share a CU's 160 KB, beyond that one 16-wave workgroup.  The kernel is
+    // bound by the softmax VALU, so what pays is many resident waves whose VALU, LDS and MFMA phases interleave -- measured
+    // (tools/attn_bench.py, us at ~65k tokens, L = 208 / 256 / 384 / 512): 4 tiles per wave x 8 waves 245 / 208 / 178 / 235,
+    // 2 tiles x 8 waves 175 / 149 / 175 / 211, 1 tile x 8 waves 127 / 115 / 194 / 229, 1 tile x 16 waves 153 / 133 / 159 / 199.
+    const int nqt = L / 16;
+#define CRH_ATTN(NW_, QT_)                                                                                                      \
+    do {                                                                                                                        \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set) {                                                                                                        \
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<NW_, QT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256)); \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((k_attn<NW_, QT_>), dim3(H, B), dim3(NW_ * 64), lds, st, (const bf16_t *)qkv,                        \
+                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);                                 \
+    } while (0)
+    static int force = -1;   // CODERAG_HIP_ATTN_CFG=<waves> (4, 8, 16; tuning only)
+    if (force < 0) {
+        const char *e = getenv("CODERAG_HIP_ATTN_CFG");
+        force = e ? atoi(e) : 0;
     }
+    const int waves = force ? force : (nqt <= 4 ? 4 : nqt <= 20 ? 8 : 16);
+    if (waves == 4)
+        CRH_ATTN(4, 1);
+    else if (waves == 8)
+        CRH_ATTN(8, 1);
+    else
+        CRH_ATTN(16, 1);
+#undef CRH_ATTN
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
