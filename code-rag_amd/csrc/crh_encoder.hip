@@ -7,8 +7,9 @@
 //
 // Kernels
 //   k_embed_ln    gather word+type+position rows, LayerNorm, also emits the key-validity bitmask (ids != pad)
-//   k_gemm_nt     C[M,N] = epi(A[M,K] . W[N,K]^T + bias): 128x128x64 tiles, v_mfma_f32_16x16x32_bf16, XOR-swizzled LDS,
-//                 register-prefetched double buffering; epilogues: bias | bias+erf-GELU | bias+residual
+//   k_gemm_nt     C[M,N] = epi(A[M,K] . W[N,K]^T + bias), small-T kernel: 256x128x64 tiles, 3-stage LDS-DMA ring (the large-T
+//                 kernel, 256x256x64 ping-pong, is g256::k_gemm_pp in crh_gemm256.hpp),
+//                 epilogues: bias | bias+erf-GELU | bias+residual
 //   k_layernorm   in-place row LayerNorm over 768 (one wave per row)
 //   k_attn        per (batch row, head): K and V of the whole row staged once in LDS, S^T = K.Q^T and O^T = V^T.P^T on
 //                 MFMA with the softmax statistics lane-local (query on the lane), V consumed through
