@@ -1,0 +1,306 @@
+// crh_rerank.hip -- hybrid re-rank of the vector branch on the device (BASELINE config 5: "vector top-k fused with
+// graph-score re-rank").
+//
+// Restates, for a batch of queries whose candidates are vector hits only, what HybridRanker.rank_results does one query
+// at a time on the host (src/lattice/query/ranking/ranker.py:24-54 -> scorer.py:80-126 score_vector_result, ranker.py:171-202
+// merge of equal keys, :46-48 stable sort by score, :204-229 per-file / total caps).  Every float expression is evaluated in
+// f64 with the reference's operand order (this file is compiled with -ffp-contract=off), so scores are identical to the
+// last bit to the Python result; the host restatement (code-rag_amd/ranking/hybrid.py) is pinned by goldens produced by the
+// reference's own code, and tests/test_rerank_gpu.py compares this kernel with it.
+//
+// The candidates' payload facts that the formulas read live on the device as per-row side columns (content length in
+// characters, degree of the chunk's graph node, dictionary codes of file / merge key / centrality key, the lower-cased
+// entity name as bytes); crh_gather_rows_* picks them for a [nq, k] candidate table straight from the search output, so no
+// payload dictionary is touched on the host before the <= max_total survivors per query are known.
+#include "crh_common.h"
+
+namespace crh {
+namespace {
+
+__device__ __forceinline__ bool bytes_equal(const uint8_t *a, const uint8_t *b, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+// `needle in hay` of Python str, on UTF-8 bytes (self-synchronising: byte containment == code-point containment)
+__device__ bool contains(const uint8_t *hay, int hn, const uint8_t *needle, int nn)
+{
+    if (nn == 0) return true;   // quirk Q8: an empty query entity is a substring of every name
+    for (int s = 0; s + nn <= hn; ++s)
+        if (bytes_equal(hay + s, needle, nn)) return true;
+    return false;
+}
+
+__global__ void k_gather_i32(int64_t n, const int64_t *__restrict__ rows, int64_t row_base, int64_t n_local, const int32_t *__restrict__ col,
+                             int32_t fill, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = rows[i] - row_base;
+    out[i] = (rows[i] >= 0 && r >= 0 && r < n_local) ? col[r] : fill;
+}
+
+__global__ void k_gather_bytes(int64_t n, const int64_t *__restrict__ rows, int64_t row_base, int64_t n_local, const uint8_t *__restrict__ col,
+                               int width, uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * width) return;
+    const int64_t c = i / width;
+    const int b = (int)(i - c * width);
+    const int64_t r = rows[c] - row_base;
+    out[i] = (rows[c] >= 0 && r >= 0 && r < n_local) ? col[r * width + b] : (uint8_t)0;
+}
+
+struct RerankArgs {
+    const float *scores;
+    const int64_t *rows;
+    crh_rerank_columns cols;
+    const crh_rerank_query *queries;   // device copy
+    double bonus;
+    int k, max_per_file, max_total, centrality_top;
+    int32_t *out_index;
+    double *out_score, *out_signals;
+    int32_t *out_count, *out_flags;
+};
+
+// one workgroup per query; dynamic LDS: [k] f64 final, 4 x [k] f64 signals, [k] i32 pos, [k] u8 alive/hybrid/keep
+__global__ __launch_bounds__(256) void k_rerank_vector(RerankArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int k = a.k, q = blockIdx.x, tid = threadIdx.x;
+    double *fin = reinterpret_cast<double *>(lds);
+    double *sig = fin + k;                                   // [4][k]: vector_similarity, query_entity_match, centrality, code_quality
+    int32_t *pos = reinterpret_cast<int32_t *>(sig + 4 * k);
+    int32_t *filec = pos + k;
+    int32_t *keyc = filec + k;
+    uint8_t *alive = reinterpret_cast<uint8_t *>(keyc + k);
+    uint8_t *hybrid = alive + k;
+    uint8_t *keepf = hybrid + k;
+    __shared__ int32_t tab_node[16], tab_deg[16];
+    __shared__ int tab_n, need_host;
+
+    const crh_rerank_query &Q = a.queries[q];
+    const size_t base = (size_t)q * k;
+    if (tid == 0) {
+        // centrality table as engine.py:348-377 builds it for a vector-only query: the first `centrality_top` hits that
+        // carry an entity name are looked up under (graph_node_id or entity_name); a lookup the graph could not answer
+        // (degree < 0) leaves no entry
+        int n = 0;
+        for (int i = 0; i < k && i < a.centrality_top; ++i) {
+            if (a.rows[base + i] < 0 || a.cols.name_len[base + i] <= 0) continue;
+            if (a.cols.degree[base + i] < 0 || n >= 16) continue;
+            tab_node[n] = a.cols.node_code[base + i];
+            tab_deg[n] = a.cols.degree[base + i];
+            ++n;
+        }
+        tab_n = n;
+        need_host = (Q.n_entities < 0 || Q.n_entities > CRH_RR_MAX_ENTITIES) ? 1 : 0;
+    }
+    __syncthreads();
+
+    for (int i = tid; i < k; i += blockDim.x) {
+        const bool valid = a.rows[base + i] >= 0;
+        alive[i] = valid;
+        hybrid[i] = 0;
+        filec[i] = a.cols.file_code[base + i];
+        keyc[i] = a.cols.key_code[base + i];
+        double em = 0.0, cen = 0.0, qual = 0.0;
+        if (valid) {
+            const int nl = a.cols.name_len[base + i];
+            const uint8_t *nm = a.cols.name + (base + i) * CRH_RR_NAME_BYTES;
+            if (nl > CRH_RR_NAME_BYTES) atomicExch(&need_host, 1);   // only a prefix is here: the host must decide this query
+            const int hn = nl < CRH_RR_NAME_BYTES ? nl : CRH_RR_NAME_BYTES;
+            bool exact = false, sub = false;
+            for (int e = 0; e < Q.n_entities && e < CRH_RR_MAX_ENTITIES; ++e) {
+                const int el = Q.entity_len[e];
+                if (el == nl && bytes_equal(nm, Q.entity[e], el)) exact = true;
+                if (contains(nm, hn, Q.entity[e], el)) sub = true;
+            }
+            em = exact ? 1.0 : sub ? 0.5 : 0.0;                       // scorer.py:92-96
+            const int node = a.cols.node_code[base + i];
+            for (int t = 0; t < tab_n; ++t)
+                if (tab_node[t] == node) {                             // first entry wins, as dict.get on the first insertion
+                    const double d = (double)tab_deg[t] / 50.0;
+                    cen = d < 1.0 ? d : 1.0;                           // min(1.0, total_degree / 50), scorer.py:48-54
+                    break;
+                }
+            const int cl = a.cols.content_len[base + i];
+            qual = cl <= 0 ? 0.0 : (cl > 100 && cl < 2000) ? 0.8 : (cl > 50 && cl < 3000) ? 0.5 : 0.3;   // scorer.py:105-114
+        }
+        const double vs = (double)a.scores[base + i];
+        sig[0 * k + i] = vs;
+        sig[1 * k + i] = em;
+        sig[2 * k + i] = cen;
+        sig[3 * k + i] = qual;
+        // scorer.py:119-124, products summed left to right
+        double f = vs * Q.vector_weight;
+        f = f + em * a.bonus;
+        f = f + cen * Q.centrality_weight;
+        f = f + qual * 0.1;
+        fin[i] = f;
+    }
+    __syncthreads();
+
+    // merge entries sharing file:entity:start_line (ranker.py:171-202): the first one absorbs the later ones in list order
+    for (int i = tid; i < k; i += blockDim.x) {
+        if (!alive[i]) continue;
+        bool first = true;
+        for (int j = 0; j < i; ++j)
+            if (a.rows[base + j] >= 0 && keyc[j] == keyc[i]) {
+                first = false;
+                break;
+            }
+        if (!first) continue;
+        double f = fin[i];
+        double s0 = sig[i], s1 = sig[k + i], s2 = sig[2 * k + i], s3 = sig[3 * k + i];
+        bool merged = false;
+        for (int j = i + 1; j < k; ++j) {
+            if (a.rows[base + j] < 0 || keyc[j] != keyc[i]) continue;
+            double c = (f + fin[j]) / 2;
+            c = c * 1.1;
+            f = c;
+            s0 = s0 > sig[j] ? s0 : sig[j];
+            s1 = s1 > sig[k + j] ? s1 : sig[k + j];
+            s2 = s2 > sig[2 * k + j] ? s2 : sig[2 * k + j];
+            s3 = s3 > sig[3 * k + j] ? s3 : sig[3 * k + j];
+            merged = true;
+        }
+        if (merged) {
+            // groups are disjoint (distinct keys): entry i is written by its owner only and read by no other owner, the
+            // absorbed entries j are only read here and dropped below
+            fin[i] = f;
+            sig[i] = s0;
+            sig[k + i] = s1;
+            sig[2 * k + i] = s2;
+            sig[3 * k + i] = s3;
+            hybrid[i] = 1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < k; i += blockDim.x) {
+        if (!alive[i]) continue;
+        for (int j = 0; j < i; ++j)
+            if (a.rows[base + j] >= 0 && keyc[j] == keyc[i]) {
+                alive[i] = 0;   // absorbed by an earlier entry (alive[] of others is not read in this loop)
+                break;
+            }
+    }
+    __syncthreads();
+
+    // stable descending sort by score (ranker.py:46-48; list.sort(reverse=True) keeps equal keys in insertion order)
+    for (int i = tid; i < k; i += blockDim.x) {
+        int p = -1;
+        if (alive[i]) {
+            p = 0;
+            const double fi = fin[i];
+            for (int j = 0; j < k; ++j)
+                if (alive[j] && (fin[j] > fi || (fin[j] == fi && j < i))) ++p;
+        }
+        pos[i] = p;
+    }
+    __syncthreads();
+    // caps (ranker.py:204-229): at most max_per_file per file in sorted order, then the first max_total of those
+    for (int i = tid; i < k; i += blockDim.x) {
+        uint8_t keep = 0;
+        if (alive[i]) {
+            int occ = 0;
+            for (int j = 0; j < k; ++j)
+                if (alive[j] && pos[j] < pos[i] && filec[j] == filec[i]) ++occ;
+            keep = occ < a.max_per_file;
+        }
+        keepf[i] = keep;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < k; i += blockDim.x) {
+        if (!keepf[i]) continue;
+        int slot = 0;
+        for (int j = 0; j < k; ++j)
+            if (keepf[j] && pos[j] < pos[i]) ++slot;
+        if (slot >= a.max_total) continue;
+        const size_t o = (size_t)q * a.max_total + slot;
+        a.out_index[o] = i;
+        a.out_score[o] = fin[i];
+        a.out_signals[o * 4 + 0] = sig[i];
+        a.out_signals[o * 4 + 1] = sig[k + i];
+        a.out_signals[o * 4 + 2] = sig[2 * k + i];
+        a.out_signals[o * 4 + 3] = sig[3 * k + i];
+        a.out_flags[o] = hybrid[i];
+        ++mine;
+    }
+    // count = number of slots written
+    __shared__ int total;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (tid == 0) a.out_count[q] = need_host ? -1 : total;
+}
+
+}  // namespace
+}  // namespace crh
+
+using namespace crh;
+
+extern "C" {
+
+int crh_gather_rows_i32(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const int32_t *col_dev, int32_t fill,
+                        int32_t *out_dev, void *stream)
+{
+    if (n < 0 || n_local < 0) return fail(CRH_E_INVALID, "gather: negative size");
+    if (n == 0) return CRH_OK;
+    if (!rows_dev || !out_dev || (n_local > 0 && !col_dev)) return fail(CRH_E_INVALID, "gather: NULL pointer");
+    hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, rows_dev, row_base,
+                       n_local, col_dev, fill, out_dev);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_gather_rows_bytes(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const uint8_t *col_dev, int width,
+                          uint8_t *out_dev, void *stream)
+{
+    if (n < 0 || n_local < 0 || width <= 0 || width > 4096) return fail(CRH_E_INVALID, "gather: bad size");
+    if (n == 0) return CRH_OK;
+    if (!rows_dev || !out_dev || (n_local > 0 && !col_dev)) return fail(CRH_E_INVALID, "gather: NULL pointer");
+    hipLaunchKernelGGL(k_gather_bytes, dim3((unsigned)ceil_div(n * width, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, rows_dev,
+                       row_base, n_local, col_dev, width, out_dev);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_rerank_vector(int nq, int k, const float *scores_dev, const int64_t *rows_dev, const crh_rerank_columns *cols,
+                      const crh_rerank_query *queries_dev, double entity_match_bonus, int max_per_file, int max_total, int centrality_top,
+                      int32_t *out_index_dev, double *out_score_dev, double *out_signals_dev, int32_t *out_count_dev, int32_t *out_flags_dev,
+                      void *stream)
+{
+    if (nq < 0 || k <= 0 || k > CRH_MAX_K) return fail(CRH_E_INVALID, "rerank: nq=%d k=%d (k in 1..%d)", nq, k, CRH_MAX_K);
+    if (max_per_file <= 0 || max_total <= 0 || centrality_top < 0) return fail(CRH_E_INVALID, "rerank: bad caps");
+    if (nq == 0) return CRH_OK;
+    if (!scores_dev || !rows_dev || !cols || !queries_dev || !out_index_dev || !out_score_dev || !out_signals_dev || !out_count_dev || !out_flags_dev)
+        return fail(CRH_E_INVALID, "rerank: NULL pointer");
+    if (!cols->content_len || !cols->degree || !cols->file_code || !cols->key_code || !cols->node_code || !cols->name_len || !cols->name)
+        return fail(CRH_E_INVALID, "rerank: NULL column");
+    RerankArgs a;
+    a.scores = scores_dev;
+    a.rows = rows_dev;
+    a.cols = *cols;
+    a.queries = queries_dev;
+    a.bonus = entity_match_bonus;
+    a.k = k;
+    a.max_per_file = max_per_file;
+    a.max_total = max_total;
+    a.centrality_top = centrality_top;
+    a.out_index = out_index_dev;
+    a.out_score = out_score_dev;
+    a.out_signals = out_signals_dev;
+    a.out_count = out_count_dev;
+    a.out_flags = out_flags_dev;
+    const size_t lds = (size_t)k * (8 * 5 + 4 * 3 + 3);
+    hipLaunchKernelGGL(k_rerank_vector, dim3(nq), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+}  // extern "C"

@@ -63,3 +63,37 @@ async def search_and_rank_batch(vector_searcher, ranker, queries, plans, graph_c
         ctx = graph_contexts[i] if graph_contexts is not None and graph_contexts[i] is not None else GraphContext()
         ranked.append(ranker.rank_results(plans[i], ctx, hits, (centrality[i] if centrality is not None else None)))
     return ranked
+
+
+async def search_and_rank_batch_device(store, reranker, host_ranker, query_vectors, plans, limit: int = 20,
+                                       language: str | None = None, project_name: str | None = None):
+    """:func:`search_and_rank_batch` for vector-only queries with the re-rank on the device: ONE corpus scan, one
+    ``crh_rerank_vector`` launch for the whole batch, and payload dictionaries touched only for the <= 50 survivors of each
+    query.  A query the device declines (``count == -1``: more than 8 plan entities, an over-long name) goes through
+    ``host_ranker`` on its full hit list, so results equal :func:`search_and_rank_batch` in every case."""
+    from .query_types import GraphContext
+    from .ranking.device import DeviceReranker
+    from .store import CollectionName
+    from .vector_search import _CODE_KEYS, _project
+    cap = get_settings().max_vector_results
+    filters = {k: v for k, v in (("language", language), ("project_name", project_name)) if v}
+    col, out, rows, scores = await store.search_rerank_batch(CollectionName.CODE_CHUNKS.value, query_vectors, plans, reranker,
+                                                             limit=min(limit, cap), filters=filters or None)
+
+    class _Hits:   # candidate position -> the flattened hit dict of query/vector_search.py:111-131, built on demand
+        def __init__(self, q):
+            self.q = q
+
+        def __getitem__(self, i):
+            return _project(col.hit(int(rows[self.q, i]), float(scores[self.q, i])), _CODE_KEYS)
+
+    ranked = []
+    for q in range(len(plans)):
+        if out.count[q] >= 0:
+            ranked.append(DeviceReranker.materialise(out, q, _Hits(q)))
+            continue
+        hits = [_project(col.hit(int(r), float(s)), _CODE_KEYS) for r, s in zip(rows[q], scores[q]) if r >= 0]
+        names = centrality_candidates(GraphContext(), hits)
+        deg = col._degrees or {}
+        ranked.append(host_ranker.rank_results(plans[q], GraphContext(), hits, {n: {"total_degree": deg[n]} for n in names if n in deg}))
+    return ranked

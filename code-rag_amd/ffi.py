@@ -27,8 +27,10 @@ EXPORTS = (
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_debug_gemm_variant", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
-    "crh_masked_mean_pool",
+    "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
 )
+
+RR_NAME_BYTES, RR_MAX_ENTITIES, RR_ENTITY_BYTES = 64, 8, 48
 
 
 class NativeError(RuntimeError):
@@ -39,6 +41,17 @@ class NativeError(RuntimeError):
 
 class Filter(C.Structure):
     _fields_ = [("col", C.c_int32), ("code", C.c_int32)]
+
+
+class RerankQuery(C.Structure):
+    """``crh_rerank_query``: one query's weights and lower-cased entity names."""
+    _fields_ = [("vector_weight", C.c_double), ("centrality_weight", C.c_double), ("n_entities", C.c_int32),
+                ("entity_len", C.c_int32 * 8), ("entity", (C.c_uint8 * 48) * 8), ("pad_", C.c_int32)]
+
+
+class RerankColumns(C.Structure):
+    """``crh_rerank_columns``: device pointers of the gathered per-candidate side data."""
+    _fields_ = [(n, C.c_void_p) for n in ("content_len", "degree", "file_code", "key_code", "node_code", "name_len", "name")]
 
 
 class SearchStats(C.Structure):
@@ -109,6 +122,9 @@ def lib() -> C.CDLL:
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
+    L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
+    L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name != "crh_last_error":
             getattr(L, name).restype = i32

@@ -1,0 +1,212 @@
+"""Device-side hybrid re-rank of vector hits (BASELINE config 5).
+
+``HybridRanker.rank_results`` (``src/lattice/query/ranking/ranker.py:24-54``) walks one query's hits in Python: about
+0.65 ms per 100 hits, 40 ms for a 64-query batch whose corpus scan takes 2.4 ms.  For candidate lists that hold vector hits
+only (no graph context -- what ``QueryEngine.search`` has when the graph finds nothing, and what BASELINE config 5
+measures), the same arithmetic runs in one kernel launch over the whole batch (``crh_rerank_vector``), reading the payload
+facts it needs from per-row SIDE COLUMNS that live on the device beside the vectors:
+
+    content_len  len(payload["content"])            -> code_quality       (scorer.py:105-114)
+    degree       total_degree of the row's node      -> centrality         (scorer.py:48-54; -1 = unknown to the graph)
+    file_code    dictionary code of file_path        -> per-file cap       (ranker.py:204-229)
+    key_code     code of file:entity_name:start_line -> merge of duplicates (models.py:55-56, ranker.py:171-202)
+    node_code    code of graph_node_id or entity_name-> centrality lookup key
+    name         lower-cased entity name, 64 bytes   -> query_entity_match (scorer.py:92-96)
+
+Results are bit-identical to ``HybridRanker`` (f64, same operand order); ``tests/test_rerank_gpu.py`` checks that.  Only
+the <= 50 survivors per query are turned into ``RankedResult`` objects on the host.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Sequence
+
+import numpy as np
+
+from .. import ffi
+from ..query_types import ResultSource
+from .model import RankedResult, RankingConfig, RankingSignal
+
+SIGNALS = (RankingSignal.VECTOR_SIMILARITY.value, RankingSignal.QUERY_ENTITY_MATCH.value,
+           RankingSignal.CENTRALITY.value, RankingSignal.CODE_QUALITY.value)
+
+
+def node_key(payload: dict[str, Any]) -> str:
+    """The centrality lookup key of a vector hit: ``graph_node_id or entity_name`` (scorer.py:48-54 through
+    ranker.py:253-264, where ``qualified_name`` is the hit's ``graph_node_id``)."""
+    return payload.get("graph_node_id") or payload.get("entity_name", "") or ""
+
+
+def merge_key(payload: dict[str, Any]) -> str:
+    return f"{payload.get('file_path', '')}:{payload.get('entity_name', '')}:{payload.get('start_line')}"
+
+
+class SideColumns:
+    """Per-row side data of one collection shard, resident on the device; rows are appended in store order."""
+
+    INT_COLS = ("content_len", "degree", "file_code", "key_code", "node_code", "name_len")
+
+    def __init__(self, device: int = 0):
+        import torch
+        self._torch = torch
+        self.device = torch.device("cuda", device)
+        self.rows = 0
+        self._host: dict[str, list] = {c: [] for c in self.INT_COLS}
+        self._names: list[bytes] = []
+        self._books: dict[str, dict[str, int]] = {"file": {}, "key": {}, "node": {}}
+        self._node_keys: list[str] = []
+        self._dev: dict[str, Any] | None = None
+
+    def _code(self, book: str, value: str) -> int:
+        b = self._books[book]
+        return b.setdefault(value, len(b) + 1)
+
+    def append(self, payloads: Sequence[dict[str, Any] | None]) -> None:
+        """Rows in store order; ``None`` (a tombstoned row) keeps the numbering aligned."""
+        h = self._host
+        for p in payloads:
+            p = p or {}
+            content = p.get("content")
+            name = (p.get("entity_name", "") or "").lower().encode("utf-8")
+            h["content_len"].append(len(content) if content else 0)
+            h["degree"].append(-1)
+            h["file_code"].append(self._code("file", p.get("file_path", "") or ""))
+            h["key_code"].append(self._code("key", merge_key(p)))
+            nk = node_key(p)
+            h["node_code"].append(self._code("node", nk))
+            h["name_len"].append(len(name))
+            self._node_keys.append(nk)
+            self._names.append(name[: ffi.RR_NAME_BYTES].ljust(ffi.RR_NAME_BYTES, b"\0"))
+        self.rows = len(self._names)
+        self._dev = None
+
+    def set_degrees(self, total_degree: dict[str, int]) -> None:
+        """``{centrality key: total_degree}`` as the graph reports it; keys it does not know stay at -1."""
+        self._host["degree"] = [int(total_degree.get(k, -1)) for k in self._node_keys]
+        self._dev = None
+
+    def set_int_column(self, name: str, values) -> None:
+        """Bulk load of one column (synthetic corpora: arrays generated without payload dictionaries)."""
+        v = np.asarray(values, dtype=np.int32)
+        if v.shape != (self.rows,):
+            raise ValueError(f"column {name} needs {self.rows} values")
+        self._host[name] = v
+        self._dev = None
+
+    @classmethod
+    def from_arrays(cls, device: int, **cols) -> "SideColumns":
+        """Columns given as arrays (``name`` as uint8 [rows, 64]); no dictionaries are kept."""
+        self = cls(device)
+        self.rows = int(len(cols["content_len"]))
+        self._host = {c: np.asarray(cols[c], dtype=np.int32) for c in cls.INT_COLS}
+        self._names = np.ascontiguousarray(cols["name"], dtype=np.uint8).reshape(self.rows, ffi.RR_NAME_BYTES)
+        return self
+
+    def _resident(self) -> dict[str, Any]:
+        if self._dev is None:
+            t = self._torch
+            dev = {c: t.from_numpy(np.asarray(self._host[c], dtype=np.int32)).to(self.device) for c in self.INT_COLS}
+            names = self._names if isinstance(self._names, np.ndarray) else \
+                np.frombuffer(b"".join(self._names), dtype=np.uint8).reshape(self.rows, ffi.RR_NAME_BYTES)
+            dev["name"] = t.from_numpy(np.array(names, dtype=np.uint8)).to(self.device)
+            self._dev = dev
+        return self._dev
+
+    def gather(self, rows_dev, row_base: int = 0, stream: int = 0) -> dict[str, Any]:
+        """Side data of a candidate table ``rows_dev`` (int64 CUDA tensor [nq, k]); rows of other shards give zeros
+        (degree: 0 as well, so that the shards' gathers add up -- the owner contributes the real value)."""
+        t = self._torch
+        dev = self._resident()
+        n = int(rows_dev.numel())
+        out = {}
+        L = ffi.lib()
+        for c in self.INT_COLS:
+            o = t.empty((n,), dtype=t.int32, device=self.device)
+            ffi.check(L.crh_gather_rows_i32(n, rows_dev.data_ptr(), row_base, self.rows, dev[c].data_ptr(), 0, o.data_ptr(), stream))
+            out[c] = o
+        o = t.empty((n, ffi.RR_NAME_BYTES), dtype=t.uint8, device=self.device)
+        ffi.check(L.crh_gather_rows_bytes(n, rows_dev.data_ptr(), row_base, self.rows, dev["name"].data_ptr(), ffi.RR_NAME_BYTES,
+                                          o.data_ptr(), stream))
+        out["name"] = o
+        return out
+
+
+@dataclass
+class RerankOutput:
+    """Per query, in final order: ``index[q, :count[q]]`` are positions in the candidate list; ``count[q] == -1`` means the
+    device declined the query (more than 8 entities, an entity name longer than 64 bytes) and the host ranker must run."""
+    index: np.ndarray     # int32 [nq, max_total]
+    score: np.ndarray     # float64 [nq, max_total]
+    signals: np.ndarray   # float64 [nq, max_total, 4] in SIGNALS order
+    count: np.ndarray     # int32 [nq]
+    hybrid: np.ndarray    # bool [nq, max_total]
+
+
+def pack_queries(plans, config: RankingConfig) -> np.ndarray:
+    """``crh_rerank_query`` array (as bytes) from query plans: the intent's weights and the set of lower-cased entity names
+    (ranker.py:33-35).  Too many or too long entities are signalled with n_entities = -1."""
+    arr = (ffi.RerankQuery * len(plans))()
+    for q, plan in zip(arr, plans):
+        w = config.weights_for(plan.primary_intent)
+        q.vector_weight, q.centrality_weight = w["vector_weight"], w["centrality_weight"]
+        names = sorted({e.name.lower() for e in plan.entities})
+        enc = [n.encode("utf-8") for n in names]
+        if len(enc) > ffi.RR_MAX_ENTITIES or any(len(b) > ffi.RR_ENTITY_BYTES for b in enc):
+            q.n_entities = -1
+            continue
+        q.n_entities = len(enc)
+        for i, b in enumerate(enc):
+            q.entity_len[i] = len(b)
+            C.memmove(C.addressof(q.entity[i]), b, len(b))
+    return np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+
+
+class DeviceReranker:
+    """``HybridRanker`` for batches of vector-only candidate lists, on the device."""
+
+    def __init__(self, config: RankingConfig | None = None, centrality_top: int = 5, device: int = 0):
+        import torch
+        self._torch = torch
+        self.config = config or RankingConfig()
+        self.centrality_top = centrality_top   # QueryEngine looks up the first 5 vector hits (engine.py:358-362)
+        self.device = torch.device("cuda", device)
+
+    def rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int = 0) -> RerankOutput:
+        t = self._torch
+        nq, k = (int(v) for v in scores_dev.shape)
+        if len(plans) != nq:
+            raise ValueError(f"{len(plans)} plans for {nq} candidate lists")
+        mt = self.config.max_total
+        qdev = t.from_numpy(pack_queries(plans, self.config)).to(self.device)
+        cc = ffi.RerankColumns(*(cols[c].data_ptr() for c in ("content_len", "degree", "file_code", "key_code", "node_code", "name_len", "name")))
+        o_idx = t.full((nq, mt), -1, dtype=t.int32, device=self.device)
+        o_sc = t.zeros((nq, mt), dtype=t.float64, device=self.device)
+        o_sig = t.zeros((nq, mt, 4), dtype=t.float64, device=self.device)
+        o_cnt = t.zeros((nq,), dtype=t.int32, device=self.device)
+        o_flg = t.zeros((nq, mt), dtype=t.int32, device=self.device)
+        ffi._typed(scores_dev, "float32", "scores")
+        ffi._typed(rows_dev, "int64", "rows")
+        ffi.check(ffi.lib().crh_rerank_vector(nq, k, scores_dev.data_ptr(), rows_dev.data_ptr(), C.byref(cc), qdev.data_ptr(),
+                                              self.config.entity_match_bonus, self.config.max_per_file, mt, self.centrality_top,
+                                              o_idx.data_ptr(), o_sc.data_ptr(), o_sig.data_ptr(), o_cnt.data_ptr(), o_flg.data_ptr(), stream))
+        return RerankOutput(o_idx.cpu().numpy(), o_sc.cpu().numpy(), o_sig.cpu().numpy(), o_cnt.cpu().numpy(),
+                            o_flg.cpu().numpy().astype(bool))
+
+    @staticmethod
+    def materialise(out: RerankOutput, q: int, hits: Sequence[dict[str, Any]]) -> list[RankedResult]:
+        """The survivors of query ``q`` as ``RankedResult`` objects, built from the flattened hit dicts of its candidate
+        list exactly as ``HybridRanker._from_vector_hit`` builds them (fields of an absorbed duplicate are not filled in --
+        the device keeps no payload text; a caller that needs them uses the host ranker)."""
+        res = []
+        for s in range(int(out.count[q])):
+            hit = hits[int(out.index[q, s])]
+            res.append(RankedResult(
+                file_path=hit.get("file_path", ""), entity_name=hit.get("entity_name", ""), entity_type=hit.get("entity_type", ""),
+                qualified_name=hit.get("graph_node_id"), content=hit.get("content"), summary=hit.get("summary"),
+                start_line=hit.get("start_line"), end_line=hit.get("end_line"), graph_node_id=hit.get("graph_node_id"),
+                final_score=float(out.score[q, s]),
+                signal_scores={name: float(out.signals[q, s, j]) for j, name in enumerate(SIGNALS)},
+                source=ResultSource.HYBRID.value if out.hybrid[q, s] else ResultSource.VECTOR.value))
+        return res

@@ -82,6 +82,25 @@ class _Collection:
         self.row_of_id: dict[str, int] = {}
         self.codebooks: list[dict[Any, int]] = [dict() for _ in self.keys]   # value -> code (>= 1; 0 = missing/None)
         self.rows_by_code: list[dict[int, set[int]]] = [dict() for _ in self.keys]
+        self._side = None          # ranking.device.SideColumns of the rows appended so far (built on first use)
+        self._degrees: dict[str, int] | None = None
+        self._device = device
+
+    def side_columns(self):
+        """Per-row side data for the device re-rank (ranking/device.py), extended lazily as rows are appended."""
+        from .ranking.device import SideColumns
+        if self._side is None:
+            self._side = SideColumns(self._device)
+        if self._side.rows < len(self.payloads):
+            self._side.append(self.payloads[self._side.rows:])
+            if self._degrees is not None:
+                self._side.set_degrees(self._degrees)
+        return self._side
+
+    def set_degrees(self, total_degree: dict[str, int]) -> None:
+        self._degrees = dict(total_degree)
+        if self._side is not None:
+            self._side.set_degrees(self._degrees)
 
     # -- payload coding
     def _encode(self, payload: dict) -> list[int]:
@@ -411,6 +430,38 @@ class HipVectorStore:
             q = np.asarray(query_vectors, dtype=np.float32)
             col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
             return [[col.hit(int(r), float(s)) for s, r in zip(srow, rrow) if r >= 0] for srow, rrow in zip(scores, rows)]
+        except Exception as e:
+            raise VectorStoreError(f"Failed to search {collection}", cause=e)
+
+    async def set_graph_degrees(self, collection: str, total_degree: dict[str, int]) -> None:
+        """``{graph_node_id or entity_name: total_degree}`` for the device re-rank's centrality signal (the reference asks
+        Memgraph per query, query/engine.py:348-377; a store that keeps the degrees beside the vectors answers on the device)."""
+        await self._run(lambda: self._col(collection).set_degrees(total_degree))
+
+    async def search_rerank_batch(self, collection: str, query_vectors, plans, reranker, limit: int = 20,
+                                  filters: dict[str, Any] | None = None):
+        """One corpus scan for all queries, then the hybrid re-rank of every candidate list on the device
+        (``ranking.device.DeviceReranker``): returns ``(collection, output, rows, scores)`` -- the :class:`RerankOutput` and the
+        host copies of the [nq, limit] candidate rows / scores it indexes.  Payloads are read only for the survivors (see
+        ``engine_helpers.search_and_rank_batch_device``)."""
+        import torch
+        try:
+            def work():
+                col = self._col(collection)
+                dfilt = col.device_filters(filters)
+                q = np.ascontiguousarray(np.asarray(query_vectors, dtype=np.float32))
+                nq = q.shape[0]
+                dev = torch.device("cuda", self._device)
+                s = torch.full((nq, limit), float("-inf"), dtype=torch.float32, device=dev)
+                r = torch.full((nq, limit), -1, dtype=torch.int64, device=dev)
+                if dfilt is not None and limit > 0 and nq > 0:
+                    qd = torch.from_numpy(q).to(dev)
+                    col.index.search(qd, limit, filters=dfilt, out_scores=s, out_rows=r,
+                                     stream=torch.cuda.current_stream(dev).cuda_stream)
+                    col.index.search_finish(torch.cuda.current_stream(dev).cuda_stream)
+                out = reranker.rank(s, r, col.side_columns().gather(r), plans)
+                return col, out, r.cpu().numpy(), s.cpu().numpy()
+            return await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)
 

@@ -155,6 +155,57 @@ int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int qu
 int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev,
                    float *out_scores_dev, int64_t *out_rows_dev, void *stream);
 
+/* ---- hybrid re-rank of the vector branch (BASELINE config 5; replaces, for vector-only candidate lists, the per-query
+ * host loop of HybridRanker.rank_results, src/lattice/query/ranking/ranker.py:24-54 + scorer.py:80-126 + ranker.py:171-229).
+ * Scores are computed in f64 with the reference's operand order: bit-identical to the Python result. */
+#define CRH_RR_NAME_BYTES 64    /* bytes of the lower-cased entity name kept per row */
+#define CRH_RR_MAX_ENTITIES 8   /* query entities per query handled on the device */
+#define CRH_RR_ENTITY_BYTES 48
+
+/* What score_vector_result reads of one query (scorer.py:80-126): RankingConfig.weights_for(plan.primary_intent) and the
+ * lower-cased names of plan.entities.  n_entities outside 0..CRH_RR_MAX_ENTITIES sends the query back to the host. */
+typedef struct crh_rerank_query {
+    double vector_weight;
+    double centrality_weight;
+    int32_t n_entities;
+    int32_t entity_len[CRH_RR_MAX_ENTITIES];
+    uint8_t entity[CRH_RR_MAX_ENTITIES][CRH_RR_ENTITY_BYTES];
+    int32_t pad_;
+} crh_rerank_query;
+
+/* Per-candidate side data, device arrays of nq*k entries in candidate order (crh_gather_rows_* fills them from per-row
+ * columns): len(content) in characters (0 = empty); total_degree of the row's graph node (-1 = the graph has no answer);
+ * dictionary codes of file_path, of the merge key "file:entity_name:start_line" (models.py:55-56) and of the centrality
+ * key (graph_node_id or entity_name, scorer.py:48-54); the lower-cased UTF-8 entity name, zero padded to
+ * CRH_RR_NAME_BYTES, with its true byte length (a longer name sends its query back to the host). */
+typedef struct crh_rerank_columns {
+    const int32_t *content_len;
+    const int32_t *degree;
+    const int32_t *file_code;
+    const int32_t *key_code;
+    const int32_t *node_code;
+    const int32_t *name_len;
+    const uint8_t *name;
+} crh_rerank_columns;
+
+/* out[i] = col[rows[i] - row_base] for rows owned by this shard (row_base <= row < row_base + n_local), `fill` (bytes: 0)
+ * otherwise -- so that the columns of a merged multi-shard candidate list are the sum over the shards' gathers. */
+int crh_gather_rows_i32(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const int32_t *col_dev, int32_t fill,
+                        int32_t *out_dev, void *stream);
+int crh_gather_rows_bytes(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const uint8_t *col_dev, int width,
+                          uint8_t *out_dev, void *stream);
+
+/* Re-rank nq candidate lists of k vector hits (scores/rows as crh_search or crh_merge_topk return them; rows < 0 = padding).
+ * The centrality table of a query holds the first `centrality_top` named hits, as QueryEngine._get_centrality_scores builds
+ * it for a query without graph results (query/engine.py:348-377).  Outputs, per query, in final order: index into the
+ * candidate list, final score, the four signals (vector_similarity, query_entity_match, centrality, code_quality), flag
+ * bit 0 = "hybrid" (entries sharing a merge key were fused); out_count[q] = survivors (<= max_total), or -1 when the host
+ * must rank this query (too many entities, a truncated name).  `queries_dev` is a device copy of nq crh_rerank_query. */
+int crh_rerank_vector(int nq, int k, const float *scores_dev, const int64_t *rows_dev, const crh_rerank_columns *cols,
+                      const crh_rerank_query *queries_dev, double entity_match_bonus, int max_per_file, int max_total,
+                      int centrality_top, int32_t *out_index_dev, double *out_score_dev, double *out_signals_dev,
+                      int32_t *out_count_dev, int32_t *out_flags_dev, void *stream);
+
 /* Filter-only fetch: first `limit` alive rows (ascending) matching the filters, host int64 out;
  * n_out receives how many.  Replaces QdrantManager.search(query_vector=None, ...) as used by
  * query/context/builder.py:111-119 and the scroll of embeddings/client.py:178-202. */

@@ -68,3 +68,36 @@ def test_binding_refuses_pointers_the_c_side_would_misread():
         ffi._out(torch.zeros((4, 7), dtype=torch.int64), "int64", "out_rows", (4, 8))
     with pytest.raises(ffi.NativeError, match="int64"):
         ffi._out(np.zeros((4, 8), np.int32), "int64", "out_rows", (4, 8))
+
+
+def test_rerank_structs_match_the_header():
+    """ctypes mirrors of crh_rerank_query / crh_rerank_columns have the size the C compiler gives the header's structs."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from coderag_amd import ffi
+    src = '#include <stdio.h>\n#include "coderag_hip.h"\nint main(){printf("%zu %zu %d %d %d", sizeof(crh_rerank_query), ' \
+          'sizeof(crh_rerank_columns), CRH_RR_NAME_BYTES, CRH_RR_MAX_ENTITIES, CRH_RR_ENTITY_BYTES);return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        got = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert [int(v) for v in got] == [C.sizeof(ffi.RerankQuery), C.sizeof(ffi.RerankColumns), ffi.RR_NAME_BYTES,
+                                     ffi.RR_MAX_ENTITIES, ffi.RR_ENTITY_BYTES]
+
+
+def test_rerank_query_packing():
+    from types import SimpleNamespace as NS
+    import ctypes as C
+    from coderag_amd import ffi
+    from coderag_amd.ranking import RankingConfig
+    from coderag_amd.ranking.device import pack_queries
+    plans = [NS(primary_intent="find_similar", entities=[NS(name="Repo"), NS(name="repo"), NS(name="Löwe")]),
+             NS(primary_intent="unknown", entities=[NS(name="x" * 60)])]
+    raw = pack_queries(plans, RankingConfig())
+    arr = (ffi.RerankQuery * 2).from_buffer_copy(raw.tobytes())
+    assert (arr[0].vector_weight, arr[0].centrality_weight) == (0.8, 0.2)
+    assert arr[0].n_entities == 2                                    # the set of lower-cased names
+    names = {bytes(arr[0].entity[i][: arr[0].entity_len[i]]).decode() for i in range(2)}
+    assert names == {"repo", "löwe"}
+    assert arr[1].n_entities == -1                                   # longer than CRH_RR_ENTITY_BYTES: the host ranks it
