@@ -92,6 +92,77 @@ def time_search(torch, idx, qd, k, filters, steps, warmup):
             "candidates": st.get("candidates"), "fallback_used": st.get("fallback_used")}
 
 
+def c5_leg(np, torch, ffi, dev, rows, steps, warmup):
+    from types import SimpleNamespace as NS
+    from coderag_amd.query_types import GraphContext, QueryIntent
+    from coderag_amd.ranking import HybridRanker
+    from coderag_amd.ranking.device import DeviceReranker, SideColumns, SIGNALS
+    from coderag_amd.engine_helpers import centrality_candidates
+    D, nq, k = 768, 64, 100
+    idx, _, _, _ = build_corpus(torch, ffi, dev, rows, ffi.DTYPE_BF16, "gaussian", 0, 1)
+    vocab = [f"fn_{i}" for i in range(2000)] + ["UserRepository", "verify_password", "parse_file", ""]
+    r99, r98 = np.random.default_rng(99), np.random.default_rng(98)
+    name_id = r99.integers(0, len(vocab), rows)
+    names = np.zeros((len(vocab), 64), np.uint8)
+    nlen = np.zeros(len(vocab), np.int32)
+    for i, v in enumerate(vocab):
+        b = v.lower().encode()
+        names[i, :len(b)] = np.frombuffer(b, np.uint8)
+        nlen[i] = len(b)
+    file_code = (np.arange(rows) // 7 + 1).astype(np.int32)                     # 7 chunks per file
+    side = SideColumns.from_arrays(0, content_len=np.clip(np.round(np.exp(r99.normal(np.log(400.0), 1.0, rows))), 0, 20000),
+                                   degree=np.minimum(r98.zipf(1.6, rows), 500) - 1, file_code=file_code,
+                                   key_code=np.arange(1, rows + 1), node_code=name_id + 1, name_len=nlen[name_id], name=names[name_id])
+    intents = [i.value for i in QueryIntent]
+    plans = [NS(primary_intent=intents[q % len(intents)], entities=[NS(name=vocab[(37 * q) % 2000]), NS(name="Repository")]) for q in range(nq)]
+    qd = torch.from_numpy(np.random.default_rng(7).standard_normal((nq, D)).astype(np.float32)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    r = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    rr = DeviceReranker()
+
+    def once():
+        idx.search(qd, k, out_scores=s, out_rows=r, stream=stream)
+        idx.search_finish(stream)
+        return rr.rank(s, r, side.gather(r, stream=stream), plans, stream=stream)
+    for _ in range(warmup):
+        out = once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = once()                       # (rank() ends with the D2H copy of the survivors: the step is complete)
+    wall = (time.perf_counter() - t0) / steps
+    # re-rank alone (gather + kernel + D2H), same candidates
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rr.rank(s, r, side.gather(r, stream=stream), plans, stream=stream)
+    rerank = (time.perf_counter() - t0) / steps
+    # parity + host cost: HybridRanker over hit dicts rebuilt from the side arrays for these candidates
+    rows_h, scores_h = r.cpu().numpy(), s.cpu().numpy()
+    host = HybridRanker()
+    cl, dg = np.asarray(side._host["content_len"]), np.asarray(side._host["degree"])
+    ok, t_host = True, 0.0
+    for q in range(nq):
+        hits = [{"score": float(sc), "file_path": f"f{file_code[ro]}", "entity_name": vocab[name_id[ro]], "entity_type": "function",
+                 "graph_node_id": None, "content": "x" * int(cl[ro]) if cl[ro] else None, "start_line": int(ro), "end_line": 0}
+                for ro, sc in zip(rows_h[q], scores_h[q]) if ro >= 0]
+        cand = centrality_candidates(GraphContext(), hits)
+        deg_of = {vocab[name_id[ro]]: int(dg[ro]) for ro in rows_h[q][:5] if ro >= 0}
+        table = {n: {"total_degree": deg_of[n]} for n in cand if deg_of.get(n, -1) >= 0}
+        t1 = time.perf_counter()
+        want = host.rank_results(plans[q], GraphContext(), hits, table)
+        t_host += time.perf_counter() - t1
+        got = DeviceReranker.materialise(out, q, hits)
+        ok = ok and len(got) == len(want) and all(g.final_score == w.final_score and g.entity_name == w.entity_name and g.start_line == w.start_line
+                                                   and [g.signal_scores[n] for n in SIGNALS] == [w.signal_scores[n] for n in SIGNALS]
+                                                   for g, w in zip(got, want))
+    idx.close()
+    log(f"  C5: scan+rerank {wall * 1e3:.3f} ms/batch, rerank part {rerank * 1e3:.3f} ms, host ranker {t_host * 1e3:.1f} ms, parity {ok}")
+    return {"workload": f"{rows} x {D} bf16, {nq} queries, top-{k} -> hybrid re-rank (vector branch) -> <= 50 per query",
+            "scan_plus_rerank_ms_per_batch": wall * 1e3, "rerank_ms_per_batch": rerank * 1e3, "queries_per_s": nq / wall,
+            "host_hybrid_ranker_ms_per_batch": t_host * 1e3, "identical_to_host_ranker": bool(ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
@@ -160,6 +231,14 @@ def main():
         del idx
         torch.cuda.empty_cache()
         flush()
+
+    # ---- BASELINE config 5 on one GPU: scan + device hybrid re-rank of the top-100 of 64 queries, side arrays per SURVEY 8(d)
+    # (content_len lognormal seed 99, degree Zipf seed 98), one plan per query cycling the intents
+    try:
+        res["c5"] = c5_leg(np, torch, ffi, dev, args.rows, args.steps, args.warmup)
+    except Exception as e:   # the matrix's other rows stay useful
+        res["c5"] = {"error": repr(e)}
+    flush()
 
     if not args.skip_encoder:
         from coderag_amd import encoder as drv
