@@ -100,6 +100,29 @@ class ShardedIndex:
             out_r.copy_(torch.from_numpy(mr))
         return out_s, out_r
 
+    # ------------------------------------------------------------------ hybrid re-rank (BASELINE config 5)
+    def attach_side_columns(self, side) -> None:
+        """``side``: this shard's per-row side data (``ranking.device.SideColumns`` or anything with the same
+        ``gather(rows, row_base=...)``).  The dictionary codes in it (file / merge key / centrality key) must come from
+        dictionaries shared by all shards, since candidates of different shards are compared by code."""
+        self.side = side
+
+    def gather_columns(self, rows) -> dict[str, Any]:
+        """Side data of a merged candidate table (global rows, identical on every rank): every rank gathers the rows it
+        owns (the others give zeros) and one all-reduce(sum) per column completes the table on all ranks -- [nq, k] small
+        integers plus 64 name bytes per candidate, ~0.6 MB at nq=64, k=100."""
+        cols = self.side.gather(rows, row_base=self.row_base)
+        if self.world > 1:
+            for name in cols:
+                self._dist.all_reduce(cols[name], op=self._dist.ReduceOp.SUM, group=self.group)
+        return cols
+
+    def search_rerank(self, queries, k: int, plans, reranker, filters=None):
+        """Global top-k of every query, then the hybrid re-rank of the merged lists (identical on every rank).
+        Returns (RerankOutput, merged scores, merged global rows)."""
+        s, r = self.search(queries, k, filters=filters)
+        return reranker.rank(s, r, self.gather_columns(r), plans), s, r
+
     def owner_of(self, global_row: int) -> tuple[int, int]:
         """global row id -> (rank, local row)."""
         return int(global_row) // self.shard_capacity, int(global_row) % self.shard_capacity

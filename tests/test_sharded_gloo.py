@@ -58,6 +58,26 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.all_gather(gathered, rows)
         assert all(torch.equal(gathered[0], g) for g in gathered), "ranks disagree on the merged result"
     assert sh.owner_of(int(rows[0, 0])) == (int(rows[0, 0]) // cap, int(rows[0, 0]) % cap)
+
+    # side columns of the merged list (config 5): each rank contributes the rows it owns, one all-reduce completes them
+    class FakeSide:
+        def __init__(self, n_local):
+            self.n = n_local
+
+        def gather(self, rows_t, row_base=0):
+            r = rows_t.numpy().reshape(-1) - row_base
+            own = (rows_t.numpy().reshape(-1) >= 0) & (r >= 0) & (r < self.n)
+            glob = rows_t.numpy().reshape(-1)
+            val = np.where(own, (glob % 1000) * 3 + 1, 0).astype(np.int32)          # a function of the GLOBAL row id
+            name = np.where(own[:, None], (glob[:, None] + np.arange(4)[None, :]) % 251, 0).astype(np.uint8)
+            return {"content_len": torch.from_numpy(val), "name": torch.from_numpy(name)}
+
+    sh.attach_side_columns(FakeSide(counts[rank]))
+    s, rows = sh.search(q, 10)
+    cols = sh.gather_columns(rows)
+    flat = rows.numpy().reshape(-1)
+    assert np.array_equal(cols["content_len"].numpy(), ((flat % 1000) * 3 + 1).astype(np.int32)), f"rank {rank}: column not completed"
+    assert np.array_equal(cols["name"].numpy(), ((flat[:, None] + np.arange(4)[None, :]) % 251).astype(np.uint8))
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     dist.destroy_process_group()
 
