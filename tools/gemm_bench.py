@@ -18,11 +18,18 @@ for name, N, K in shapes:
     w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
     b = torch.randn((N,), generator=g).to(dev)
     y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
-    res = {}
+    res = torch.randn((T, N), generator=g).to(dev, torch.bfloat16) if N == 768 else None
+    gam = torch.ones((768,), device=dev)
+    results = {}
     for rnd in range(5):
         for v in VARIANTS:
+            if v == 102 and N != 768:
+                continue
             def call():
-                if v >= 100:
+                if v == 102:   # GEMM + residual + LayerNorm (N must be 768)
+                    ffi.check(L.crh_gemm_bf16_bias_res_ln(a.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), gam.data_ptr(), gam.data_ptr(),
+                                                          1e-5, y.data_ptr(), T, N, K, 0))
+                elif v >= 100:
                     ffi.check(L.crh_gemm_bf16_bias(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v - 100, 0))
                 else:
                     ffi.check(L.crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, v, 0))
@@ -34,8 +41,10 @@ for name, N, K in shapes:
                 call()
             e1.record()
             torch.cuda.synchronize()
-            res.setdefault(v, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+            results.setdefault(v, []).append(e0.elapsed_time(e1) / 20 * 1e3)
     fl = 2.0 * T * N * K
     for v in VARIANTS:
-        med = float(np.median(res[v]))
-        print(f"{name:6s} T={T} N={N} K={K} variant {v:2d}: median {med:7.1f} us  min {min(res[v]):7.1f}  {fl / med / 1e6:7.0f} TFLOP/s", flush=True)
+        if v not in results:
+            continue
+        med = float(np.median(results[v]))
+        print(f"{name:6s} T={T} N={N} K={K} variant {v:2d}: median {med:7.1f} us  min {min(results[v]):7.1f}  {fl / med / 1e6:7.0f} TFLOP/s", flush=True)
