@@ -805,6 +805,9 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
         if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32))
             return fail(CRH_E_INVALID, "debug gemm: variant 16 needs N%%256==0, K%%128==0, K>=256, T*K*2 < 4 GiB");
         return launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st);
+    case 19:   // EPI 2 (bias + residual, residual = y's previous contents) without the LayerNorm: isolates the residual epilogue
+        if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
+        return launch_gemm256(2, x, w, bias, y, y, T, N, K, st);
     case 17:
     case 18: {   // ablations of the ping-pong kernel's epilogue: 17 = no global stores, 18 = no epilogue
         if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
