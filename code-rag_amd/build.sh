@@ -14,3 +14,5 @@ for src in csrc/*.hip; do
   objs+=("$obj")
 done
 g++ -shared -fPIC -o lib/libcoderag_hip.so "${objs[@]}"
+# host-side native tokenizer (plain C++, no GPU code): lib/libcoderag_tok.so
+g++ -O2 -std=c++17 -shared -fPIC -pthread csrc_host/bpe_tokenizer.cpp -o lib/libcoderag_tok.so

@@ -227,10 +227,33 @@ class HipUniXcoder:
             out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
         return out
 
+    def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 32768):
+        """Batch form of tokenize + wrap + embed for a tokenizer that returns an id matrix (``NativeBpeTokenizer``):
+        ``body_ids`` int32 [n, >= max_length - 4], ``body_lens`` the untruncated counts.  Rows are wrapped as
+        [<s>, <encoder-only>, </s>] + body[: max_length - 4] + [</s>] (unixcoder_provider.py:105-122) while being packed into
+        the padded batch arrays -- no per-token Python work."""
+        torch, tok = self._torch, self.tok
+        n = int(body_lens.shape[0])
+        blen = np.minimum(body_lens.astype(np.int64), max_length - 4)
+        out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        for rows, L in self.plan_batches(blen + 4, max_tokens):
+            host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)
+            host[:, 0], host[:, 1], host[:, 2] = tok.cls_id, tok.enc_only_id, tok.sep_id
+            for r, i in enumerate(rows):
+                b = int(blen[i])
+                host[r, 3:3 + b] = body_ids[i, :b]
+                host[r, 3 + b] = tok.sep_id
+            ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+            out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
+        return out
+
     def embed_texts(self, texts, max_length: int = 512) -> list[list[float]]:
         """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text."""
         if not texts:
             return []
+        if hasattr(self.tok, "encode_bodies"):
+            body_ids, body_lens = self.tok.encode_bodies(list(texts), max_body=max_length - 4)
+            return self.embed_bodies(body_ids, body_lens, max_length).cpu().numpy().tolist()
         ids = [wrap_encoder_only(self.tok, t, max_length) for t in texts]
         return self.embed_ids(ids).cpu().numpy().tolist()
 
@@ -263,7 +286,14 @@ def load_unixcoder(model: str, extra: dict | None = None, device: int | None = N
         else:
             raise FileNotFoundError(f"{model} holds neither model.safetensors nor pytorch_model.bin")
         sd = {k[len("roberta."):] if k.startswith("roberta.") else k: v for k, v in sd.items()}
-        m = HipUniXcoder(sd, cfg, BpeTokenizer(model), device)
+        # tokenizer: the native byte-level BPE (same ids as the HF one, ~10x its rate; tests/test_tokenizer_native.py) unless
+        # CODERAG_TOKENIZER=hf asks for transformers' RobertaTokenizer
+        if os.environ.get("CODERAG_TOKENIZER", "native").lower() == "hf":
+            tok = BpeTokenizer(model)
+        else:
+            from .tokenizer_native import NativeBpeTokenizer
+            tok = NativeBpeTokenizer(model)
+        m = HipUniXcoder(sd, cfg, tok, device)
     else:
         raise FileNotFoundError(
             f"UniXcoder checkpoint {model!r} is not a local directory and hub downloads are unavailable: point "

@@ -222,3 +222,39 @@ def test_provider_end_to_end(gpu):
     assert np.allclose(many[0], many[3], atol=0, rtol=0)                 # same text, same vector (different batch slots)
     assert np.abs(np.asarray(one) - np.asarray(many[0])).max() <= 2e-2 * np.abs(np.asarray(one)).max()
     assert not np.allclose(many[0], many[1], atol=1e-3)
+
+
+def test_checkpoint_directory_with_native_tokenizer(gpu, tmp_path):
+    """A local checkpoint directory (config.json + model.safetensors + vocab.json + merges.txt, as microsoft/unixcoder-base
+    ships them; built here from seeded weights and a locally trained vocabulary) loads through load_unixcoder with the
+    native byte-level BPE, and embed_texts() equals: HF tokenizer ids -> the reference's wrapping -> embed_ids()."""
+    import glob
+    import json
+    torch, ffi, dev = _env()
+    from safetensors.torch import save_file
+    from tokenizers import ByteLevelBPETokenizer
+    from transformers import RobertaTokenizer
+    from coderag_amd import encoder as drv
+    from coderag_amd.tokenizer_native import NativeBpeTokenizer
+
+    d = str(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "code-rag_amd", "*.py")))
+    tr = ByteLevelBPETokenizer(add_prefix_space=False)
+    tr.train(files, vocab_size=3000, min_frequency=2,
+             special_tokens=["<s>", "<pad>", "</s>", "<unk>", "<mask>", "<encoder-only>", "<decoder-only>", "<encoder-decoder>"])
+    tr.save_model(d)
+    cfg = drv.EncoderConfig(vocab_size=3000, num_layers=2)
+    json.dump({"vocab_size": 3000, "hidden_size": 768, "num_hidden_layers": 2, "num_attention_heads": 12, "intermediate_size": 3072,
+               "max_position_embeddings": 1026, "type_vocab_size": 10, "layer_norm_eps": 1e-5, "pad_token_id": 1}, open(os.path.join(d, "config.json"), "w"))
+    save_file({"roberta." + k: torch.from_numpy(v) for k, v in drv.synthetic_weights(cfg, 31).items()}, os.path.join(d, "model.safetensors"))
+
+    model = drv.load_unixcoder(d, device=0)
+    assert isinstance(model.tok, NativeBpeTokenizer) and model.cfg.num_layers == 2
+    texts = [open(f, encoding="utf-8").read()[i:i + 700] for f in files[:6] for i in (0, 900, 5000)] + ["", "x", "def f():\n\treturn 'ünï'  # ✓"]
+    got = np.asarray(model.embed_texts(texts), dtype=np.float32)
+    hf = RobertaTokenizer(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    eid = hf.convert_tokens_to_ids("<encoder-only>")
+    ids = [[hf.cls_token_id, eid, hf.sep_token_id] + hf.convert_tokens_to_ids(hf.tokenize(t))[:508] + [hf.sep_token_id] for t in texts]
+    want = model.embed_ids(ids).cpu().numpy()
+    assert got.shape == (len(texts), 768) and np.array_equal(got, want)

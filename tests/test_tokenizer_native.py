@@ -1,0 +1,83 @@
+"""The native byte-level BPE tokenizer (csrc_host/bpe_tokenizer.cpp) against the HF implementation the reference uses
+(transformers RobertaTokenizer over the `tokenizers` library): identical ids on source files, on whitespace / unicode /
+contraction / special-token corner cases and on random strings, for a vocabulary trained here (no hub access)."""
+import glob
+import os
+import random
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPECIALS = ["<s>", "<pad>", "</s>", "<unk>", "<mask>", "<encoder-only>", "<decoder-only>", "<encoder-decoder>"]
+
+
+@pytest.fixture(scope="module")
+def toks(tmp_path_factory):
+    from tokenizers import ByteLevelBPETokenizer
+    from transformers import RobertaTokenizer
+    import coderag_amd  # noqa: F401
+    from coderag_amd.tokenizer_native import NativeBpeTokenizer
+    d = str(tmp_path_factory.mktemp("vocab"))
+    files = sorted(glob.glob(os.path.join(ROOT, "code-rag_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(ROOT, "tests", "*.py")))
+    tr = ByteLevelBPETokenizer(add_prefix_space=False)
+    tr.train(files, vocab_size=6000, min_frequency=2, special_tokens=SPECIALS)
+    tr.save_model(d)
+    return RobertaTokenizer(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt")), NativeBpeTokenizer(d), files
+
+
+def _hf_ids(hf, text):
+    return hf.convert_tokens_to_ids(hf.tokenize(text))
+
+
+def test_same_ids_on_source_files(toks):
+    hf, nat, files = toks
+    chunks = []
+    for f in files:
+        s = open(f, encoding="utf-8").read()
+        chunks += [s[i:i + 1500] for i in range(0, len(s), 1500)]
+    ids, lens = nat.encode_bodies(chunks, max_body=4096)
+    assert int(lens.max()) <= 4096
+    bad = [i for i, c in enumerate(chunks) if ids[i, : lens[i]].tolist() != _hf_ids(hf, c)]
+    assert not bad, f"{len(bad)} of {len(chunks)} chunks differ, first: {chunks[bad[0]][:80]!r}"
+
+
+CASES = ["", " ", "  ", "   x", "x   ", "a\n\n\nb", "\t\tif x:\r\n\t\t\treturn  y\n", "it's they're I'll we'd I've I'm don't 'sx 'S",
+         "naïve café ÀÉÎõü ß ẞ ǅ Ω", "日本語のコメント と 中文注释", "한국어 텍스트 123", "emoji 😀👍🏽 flags 🇩🇪", "x²+y³=z¼ ①②③ ٣٤٥ १२३",
+         "a\u00a0b\u2003c\u3000d\u2028e\u0085f", "zero\u200bwidth\u200djoiner", "tab\there  \t mixed \n \n", "!!!???...,,,;;; ((([[[{{{",
+         "snake_case camelCase PascalCase kebab-case SCREAMING_CASE x1y2z3 0x1F 1e-9 3.14", "<s>in text</s> and <pad><unk> <mask> here  <mask>x",
+         "a<mask>", "<mask>", "   <mask>", "<encoder-only> marker <decoder-only>", "< s > <s > <mask", "\\n \\t \"quoted\" 'single' `tick`",
+         "\x00\x01\x7f control", "end with spaces   ", "\n", "\n\n", " \n ", "x\n", "ｆｕｌｌｗｉｄｔｈ ＡＢＣ １２３", "combining e\u0301 a\u030a n\u0303"]
+
+
+def test_same_ids_on_corner_cases(toks):
+    hf, nat, _ = toks
+    for c in CASES:
+        assert nat.encode_body(c) == _hf_ids(hf, c), repr(c)
+
+
+def test_same_ids_on_random_strings(toks):
+    hf, nat, _ = toks
+    rng = random.Random(3)
+    alphabet = list("abcXYZ019 _-+*/=<>()[]{}'\"\\\n\t.,:;!?#@$%^&|~`") + ["é", "ß", "日", "本", "😀", "\u00a0", "\u2003", "١", "²", "ǅ", "'s", "'re", "<s>", "<mask>", "  "]
+    texts = ["".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 60))) for _ in range(3000)]
+    ids, lens = nat.encode_bodies(texts, max_body=512)
+    for i, t in enumerate(texts):
+        assert ids[i, : lens[i]].tolist() == _hf_ids(hf, t), repr(t)
+
+
+def test_truncation_and_threads(toks):
+    hf, nat, files = toks
+    text = open(files[0], encoding="utf-8").read()
+    full = _hf_ids(hf, text)
+    ids, lens = nat.encode_bodies([text, "x", text], max_body=37)
+    assert lens.tolist() == [len(full), 1, len(full)]
+    assert ids[0].tolist() == full[:37] and ids[2].tolist() == full[:37] and ids[1, 0] == _hf_ids(hf, "x")[0]
+    one = type(nat).__new__(type(nat))
+    one.__dict__.update(nat.__dict__)
+    one.threads = 1
+    a, la = one.encode_bodies([text] * 40, max_body=64)
+    nat.threads = 8
+    b, lb = nat.encode_bodies([text] * 40, max_body=64)
+    one._h = None                                                   # (shared handle: only `nat` frees it)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
