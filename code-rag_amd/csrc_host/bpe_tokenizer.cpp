@@ -312,6 +312,11 @@ crt_tokenizer *crt_create(int n_vocab, const char *const *tokens, const int32_t 
         auto it = t->vocab.find(unk_token);
         if (it != t->vocab.end()) t->unk_id = it->second;
     }
+    for (int b = 0; b < 256; ++b)
+        if (t->byte_id[b] < 0 && t->unk_id < 0) {   // a byte the vocabulary cannot express and no <unk> to stand in: refuse
+            delete t;
+            return nullptr;
+        }
     for (int i = 0; i < n_merges; ++i) {
         auto l = t->vocab.find(left[i]), r = t->vocab.find(right[i]);
         if (l == t->vocab.end() || r == t->vocab.end()) continue;

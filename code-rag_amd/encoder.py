@@ -214,10 +214,26 @@ class HipUniXcoder:
             batches.append((cur, cur_L))
         return batches
 
+    def _check_ids(self, ids: np.ndarray, lens=None) -> None:
+        """The embedding gather trusts its indices: an id outside the word-embedding table (a vocabulary that does not
+        belong to the checkpoint) must stop here, not fault on the device."""
+        if ids.size == 0:
+            return
+        if lens is not None:
+            ids = np.where(np.arange(ids.shape[1])[None, :] < np.asarray(lens)[:, None], ids, 0)
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= self.cfg.vocab_size:
+            raise ValueError(f"token id {hi if hi >= self.cfg.vocab_size else lo} outside the embedding table (vocab_size {self.cfg.vocab_size})")
+
     def embed_ids(self, id_lists, max_tokens: int = 32768):
         """list of token-id lists (each <= 512) -> f32 CUDA tensor [n, 768] in input order."""
         torch = self._torch
         n = len(id_lists)
+        for x in id_lists:
+            if len(x) and (min(x) < 0 or max(x) >= self.cfg.vocab_size):
+                raise ValueError(f"token id outside the embedding table (vocab_size {self.cfg.vocab_size})")
+            if len(x) > self.cfg.max_position_embeddings - 2:
+                raise ValueError(f"{len(x)} tokens exceed the position table ({self.cfg.max_position_embeddings - 2})")
         out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
         for rows, L in self.plan_batches([len(x) for x in id_lists], max_tokens):
             host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)
@@ -235,6 +251,7 @@ class HipUniXcoder:
         torch, tok = self._torch, self.tok
         n = int(body_lens.shape[0])
         blen = np.minimum(body_lens.astype(np.int64), max_length - 4)
+        self._check_ids(body_ids[:, : int(blen.max()) if n else 0], blen)
         out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
         for rows, L in self.plan_batches(blen + 4, max_tokens):
             host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)

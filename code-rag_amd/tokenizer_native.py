@@ -69,7 +69,7 @@ class NativeBpeTokenizer:
         ls = (C.c_int32 * max(1, len(sp)))(*[int(s in lstrip) for s in sp])
         self._h = lib().crt_create(len(toks), _strs(toks), ids, len(left), _strs(left), _strs(right), len(sp), _strs(sp), ls, b"<unk>")
         if not self._h:
-            raise RuntimeError("crt_create failed")
+            raise ValueError("vocab.json lacks some of the 256 byte-level symbols and has no <unk>: not a byte-level BPE vocabulary")
         self.threads = threads
         self.vocab_size = max(vocab.values()) + 1
         self.cls_id, self.pad_id, self.sep_id = vocab["<s>"], vocab["<pad>"], vocab["</s>"]

@@ -81,3 +81,24 @@ def test_truncation_and_threads(toks):
     b, lb = nat.encode_bodies([text] * 40, max_body=64)
     one._h = None                                                   # (shared handle: only `nat` frees it)
     assert np.array_equal(a, b) and np.array_equal(la, lb)
+
+
+def test_guards_against_foreign_vocabularies(tmp_path):
+    """A vocabulary that cannot express every byte (and has no <unk>) is refused at load; token ids outside the checkpoint's
+    embedding table are refused before anything reaches the device."""
+    import json
+    from types import SimpleNamespace as NS
+    import coderag_amd  # noqa: F401
+    from coderag_amd.encoder import EncoderConfig, HipUniXcoder
+    from coderag_amd.tokenizer_native import NativeBpeTokenizer
+    json.dump({"<s>": 0, "<pad>": 1, "</s>": 2, "<encoder-only>": 3, "a": 4, "b": 5}, open(tmp_path / "vocab.json", "w"))
+    open(tmp_path / "merges.txt", "w").write("#version: 0.2\na b\n")
+    with pytest.raises(ValueError, match="byte-level"):
+        NativeBpeTokenizer(str(tmp_path))
+    fake = NS(cfg=EncoderConfig(vocab_size=100))
+    HipUniXcoder._check_ids(fake, np.asarray([[5, 99, 7]], np.int32), np.asarray([3]))
+    HipUniXcoder._check_ids(fake, np.asarray([[5, 99, 1000]], np.int32), np.asarray([2]))      # the 1000 is beyond the row's length
+    with pytest.raises(ValueError, match="embedding table"):
+        HipUniXcoder._check_ids(fake, np.asarray([[5, 100, 7]], np.int32), np.asarray([3]))
+    with pytest.raises(ValueError, match="embedding table"):
+        HipUniXcoder._check_ids(fake, np.asarray([[-1, 3, 7]], np.int32), np.asarray([3]))
