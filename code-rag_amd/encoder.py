@@ -197,7 +197,7 @@ class HipUniXcoder:
         return sent
 
     # ------------------------------------------------------------------ batching
-    def plan_batches(self, lengths, max_tokens: int = 32768, max_rows: int = 1024):
+    def plan_batches(self, lengths, max_tokens: int = 65536, max_rows: int = 1024):
         """Length-bucketed batches: rows sorted by length, each batch padded to its longest row rounded up to 16 (the
         query-tile height of the attention kernel): ~4 % padded tokens on a mean-200 mix, against 16 % at granularity 64."""
         order = np.argsort(np.asarray(lengths), kind="stable")
@@ -225,7 +225,7 @@ class HipUniXcoder:
         if lo < 0 or hi >= self.cfg.vocab_size:
             raise ValueError(f"token id {hi if hi >= self.cfg.vocab_size else lo} outside the embedding table (vocab_size {self.cfg.vocab_size})")
 
-    def embed_ids(self, id_lists, max_tokens: int = 32768):
+    def embed_ids(self, id_lists, max_tokens: int = 65536):
         """list of token-id lists (each <= 512) -> f32 CUDA tensor [n, 768] in input order."""
         torch = self._torch
         n = len(id_lists)
@@ -243,7 +243,7 @@ class HipUniXcoder:
             out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
         return out
 
-    def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 32768):
+    def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 65536):
         """Batch form of tokenize + wrap + embed for a tokenizer that returns an id matrix (``NativeBpeTokenizer``):
         ``body_ids`` int32 [n, >= max_length - 4], ``body_lens`` the untruncated counts.  Rows are wrapped as
         [<s>, <encoder-only>, </s>] + body[: max_length - 4] + [</s>] (unixcoder_provider.py:105-122) while being packed into
