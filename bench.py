@@ -160,6 +160,16 @@ def main() -> None:
     exchange = np.array([ev_x[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]) if dist is not None else None
     scan_ms_total, scan_launches = idx.profile()
     idx.set_profiling(False)
+    # the same tile walk with its loads alone (no MFMA, no candidates): what this access pattern can read on this device
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        ffi.check(ffi.lib().crh_debug_read_ceiling(idx._handle(), stream))
+    e0.record()
+    for _ in range(10):
+        ffi.check(ffi.lib().crh_debug_read_ceiling(idx._handle(), stream))
+    e1.record()
+    torch.cuda.synchronize()
+    probe_ms = e0.elapsed_time(e1) / 10
     stats = idx.stats()
 
     if dist is not None:
@@ -212,6 +222,9 @@ def main() -> None:
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None,
+                     "loads_only_probe": {"GBps": alg_bytes / (probe_ms * 1e-3) / 1e9, "ms": probe_ms,
+                                          "frac_of_it": (probe_ms / scan_ms) if scan_ms > 0 else None,
+                                          "what": "crh_debug_read_ceiling: the scan's grid and nt loads without MFMA or candidate logic"},
                      "kernel": "k_scan<48,1,16,8>", "kernel_ms": scan_ms, "launches": scan_launches,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "step_ms_device": {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),

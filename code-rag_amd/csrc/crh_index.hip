@@ -596,6 +596,18 @@ int crh_index_read_rows(crh_index *h, int64_t first, int64_t n, float *out_host)
     return CRH_OK;
 }
 
+int crh_debug_read_ceiling(crh_index *h, void *stream)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    const int64_t ntiles = ceil_div(h->count, kTileRows);
+    if (ntiles == 0) return CRH_OK;
+    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    const uint32_t *mask = nullptr;
+    CRH_TRY(build_mask(h, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
+    return launch_scan<2>(h, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, h->ws_wave_cap, h->ws_qcap, h->status);
+}
+
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");

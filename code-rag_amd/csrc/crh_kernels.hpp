@@ -294,6 +294,7 @@ __device__ __forceinline__ void nt_wait(u32x4 &dst)
 
 // MODE 0 (seed):  items are sample tiles; writes gmax[item][q] = max over the tile's valid rows.
 // MODE 1 (main):  items are all tiles; rows with score >= tau[q] become candidates.
+// MODE 2 (probe): the main scan's loads only (crh_debug_read_ceiling): the HBM read rate this access pattern can reach.
 //
 // One workgroup per CU (the 96 KB query image pins that), WAVES waves each streaming its own
 // tiles: item i of wave g is i = g + j*total_waves.  Per k-step a wave issues one 1-KiB
@@ -357,8 +358,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
             const u32x4 nb1 = qs[((QB - 1) * KSTEPS + s1) * 64 + lane];
             nt_wait<RING - 1>(ring[s % RING]);   // the oldest of the RING loads in flight has landed (issue order)
             const bf16x8 xa = __builtin_bit_cast(bf16x8, ring[s % RING]);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
-            if (QB == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+            if (MODE == 2) {   // read-ceiling probe: the loads alone, kept alive by an empty asm
+                asm volatile("" ::"v"(ring[s % RING]));
+            } else {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
+                if (QB == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+            }
             const int sp = s + RING;
             const u32x4 *src = (sp < KSTEPS) ? xp + sp * 64 : xn + (sp - KSTEPS) * 64;
             nt_load(ring[s % RING], src);
@@ -367,7 +372,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        if (MODE == 0) {
+        if (MODE == 2) {
+            // nothing: the probe measures what the same access pattern reads with no arithmetic and no candidate logic
+        } else if (MODE == 0) {
             float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

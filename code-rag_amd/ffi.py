@@ -27,7 +27,7 @@ EXPORTS = (
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_debug_gemm_variant", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
-    "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
+    "crh_masked_mean_pool", "crh_debug_read_ceiling", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
 )
 
 RR_NAME_BYTES, RR_MAX_ENTITIES, RR_ENTITY_BYTES = 64, 8, 48
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.crh_debug_read_ceiling.argtypes = [vp, vp]
     L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -149,6 +149,11 @@ int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_lau
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
 
+/* Measurement support: launches the main scan's loads alone (same grid, same tile walk, same nt loads; no MFMA, no
+ * candidates) over the whole corpus -- the HBM read rate this access pattern reaches on the device at hand, the ceiling
+ * the scan's achieved GB/s is to be read against (tools/read_ceiling.py). */
+int crh_debug_read_ceiling(crh_index *h, void *stream);
+
 /* Merge nlists sorted per-shard lists ([nlists, nq, k] device f32 / int64, padded with
  * (-inf,-1)) into [nq, k]: the step after the all-gather of a row-sharded search
  * (does not exist in the reference). */
