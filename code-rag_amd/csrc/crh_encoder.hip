@@ -50,14 +50,15 @@ __device__ __forceinline__ unsigned int pack2(float a, float b)
 
 // erf-GELU for the GEMM epilogues, two elements at a time on the packed-f32 VALU: x * Phi(x) with
 // Phi(x) = 1 / (1 + 2^q(x)), q an odd degree-9 polynomial fitted (minimax, tools/fit_gelu.py) so that |x Phi(x) - gelu(x)| <= 4e-6
-// for every x (f32 evaluation; relative error <= 2.2e-3 ~ half a bf16 ulp wherever |gelu| > 1e-3).  |x| is clamped to 8 inside
-// q (beyond it Phi is 0 or 1 to 1e-12).  Per pair: 2 v_med3, 7 packed mul/fma/add, 2 v_exp, 2 v_rcp -- about a third of the
+// for every x (f32 evaluation; relative error <= 2.2e-3 ~ half a bf16 ulp wherever |gelu| > 1e-3).  No clamp is needed: the
+// polynomial q(x)/x is negative for every x (checked numerically, tools/fit_gelu.py), so q runs off to -/+inf with the right
+// sign, 2^q saturates to 0 or inf and the result to x or -0, NaN-free up to 1e30.  Per pair: 7 packed mul/fma/add, 2 v_exp,
+// 2 v_rcp -- about a third of the
 // VALU time of the scalar Abramowitz-Stegun 7.1.26 form it replaced, which matters because the FFN1 epilogue evaluates 128 of these per lane per 256x256
 // tile while the matrix pipe waits (measured: 12.7 us of a 20 us tile before).
 __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x)
 {
-    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -8.f, 8.f), __builtin_amdgcn_fmed3f(x.y, -8.f, 8.f)};
-    const f32x2_t x2 = xc * xc;
+    const f32x2_t x2 = x * x;
     const f32x2_t c9 = {-3.229079084121622e-06f, -3.229079084121622e-06f}, c7 = {8.823996904538944e-05f, 8.823996904538944e-05f},
                    c5 = {0.0003602632787078619f, 0.0003602632787078619f}, c3 = {-0.10522666573524475f, -0.10522666573524475f},
                    c1 = {-2.3020453453063965f, -2.3020453453063965f}, one = {1.f, 1.f};
@@ -65,7 +66,7 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x)
     h = __builtin_elementwise_fma(h, x2, c5);
     h = __builtin_elementwise_fma(h, x2, c3);
     h = __builtin_elementwise_fma(h, x2, c1);
-    const f32x2_t q = h * xc;
+    const f32x2_t q = h * x;
     f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
     e = e + one;
     const f32x2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
@@ -162,6 +163,46 @@ __global__ __launch_bounds__(256) void k_layernorm768(bf16_t *__restrict__ x, co
         v[4 * i + 1] = bf2f(w.x >> 16);
         v[4 * i + 2] = bf2f(w.y & 0xffffu);
         v[4 * i + 3] = bf2f(w.y >> 16);
+        s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
+    }
+    const float mu = wave_sum(s) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        u32x2 o;
+        o.x = pack2((v[4 * i] - mu) * rstd * g.x + b.x, (v[4 * i + 1] - mu) * rstd * g.y + b.y);
+        o.y = pack2((v[4 * i + 2] - mu) * rstd * g.z + b.z, (v[4 * i + 3] - mu) * rstd * g.w + b.w);
+        *reinterpret_cast<u32x2 *>(p + e) = o;
+    }
+}
+
+// LayerNorm(x + residual): the pre-LN sum is formed here in f32 (x = the GEMM output WITHOUT the residual).  Used where the
+// GEMM's residual epilogue costs more than this kernel's extra read: the O-projection (K = 768), whose epilogue would pull
+// 128 KB of cold residual per CU and tile with the matrix pipe idle (+31 us per call at 65 k tokens against +18 us here).
+__global__ __launch_bounds__(256) void k_layernorm768_res(bf16_t *__restrict__ x, const bf16_t *__restrict__ res, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bf16_t *p = x + (size_t)r * 768;
+    const bf16_t *pr = res + (size_t)r * 768;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p + i * 256 + lane * 4);
+        const u32x2 z = *reinterpret_cast<const u32x2 *>(pr + i * 256 + lane * 4);
+        v[4 * i] = bf2f(w.x & 0xffffu) + bf2f(z.x & 0xffffu);
+        v[4 * i + 1] = bf2f(w.x >> 16) + bf2f(z.x >> 16);
+        v[4 * i + 2] = bf2f(w.y & 0xffffu) + bf2f(z.y & 0xffffu);
+        v[4 * i + 3] = bf2f(w.y >> 16) + bf2f(z.y >> 16);
         s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
     }
     const float mu = wave_sum(s) * (1.f / 768.f);
@@ -843,6 +884,14 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
     if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_gemm256(T, N, K) && K <= 1024 && y != residual) {
+        // short K: the residual joins in the LayerNorm kernel instead of the GEMM epilogue (see k_layernorm768_res)
+        CRH_TRY(launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st));
+        hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma,
+                           beta, eps, T);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     if (use_gemm256(T, N, K)) {
         CRH_TRY(launch_gemm256(2, x, w, bias, residual, y, T, N, K, st));
         hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
