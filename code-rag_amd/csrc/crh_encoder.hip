@@ -849,6 +849,14 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
     case 19:   // EPI 2 (bias + residual, residual = y's previous contents) without the LayerNorm: isolates the residual epilogue
         if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
         return launch_gemm256(2, x, w, bias, y, y, T, N, K, st);
+    case 20: {   // no epilogue + 1.5x LDS-DMA + extra fragment reads (what a two-pass half-height schedule would load)
+        if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
+        const dim3 grid256(gemm256_grid(T, N)), block(g256::WAVES * 64);
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        hipLaunchKernelGGL((g256::k_gemm_pp<0, 6>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     case 17:
     case 18: {   // ablations of the ping-pong kernel's epilogue: 17 = no global stores, 18 = no epilogue
         if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");

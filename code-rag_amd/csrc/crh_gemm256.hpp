@@ -42,7 +42,9 @@ constexpr int R_AH0 = 0, R_WH0 = 1, R_WH1 = 2, R_AH1 = 3;
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
 // EPI: 0 bias, 1 bias + erf-GELU, 2 bias + residual.  M arbitrary (guarded), N % 256 == 0, K % 128 == 0, K >= 256.
-// DBG (timing ablations, wrong results): 1 = no global stores in the epilogue, 2 = no epilogue at all
+// DBG (timing ablations, wrong results): 1 = no global stores in the epilogue, 2 = no epilogue at all, 4 = 1.5x the LDS-DMA
+// (one more half-tile every other phase, into the idle epilogue images) and 4 more fragment reads per phase -- the load a
+// two-pass schedule with half-height wave tiles would put on the main loop
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
                                                         const float *__restrict__ bias, const bf16_t *__restrict__ R,
@@ -232,10 +234,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
     // after the advance, to this one in phases 2-3
     int m0 = 0, n0 = 0;   // origin of the tile being computed
     float4 bv[4];         // its bias fragment, fetched under the tile's last 16 MFMAs (FW1 is dead by then)
+    auto extra_load = [&](const bool dma) __attribute__((always_inline)) {
+        if (!(DBG & 4)) return;
+        if (dma && c_more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(W) + (pw + ((uint32_t)(i * 8) * (uint32_t)K + (uint32_t)c_k0) * 2u);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + 2 * kBuf + wave * 2048 + i * 1024), 16, 0, 0);
+            }
+        }
+        uint32_t a0 = rw;
+        asm volatile("" : "+v"(a0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 v = lds_read((a0 ^ (i & 1 ? 64u : 0u)) + (i >> 1) * 2048);
+            asm volatile("" ::"v"(v));
+        }
+    };
     auto ktile = [&](const int B, const bool first, const bool last) __attribute__((always_inline)) {
         read_a(B, 0);
         read_w(B, 0, FW0);
         stage(R_WH1, B ^ 1);
+        extra_load(true);
         mem_end();
         mfma16(0, 0, FW0, first);
         mfma_end();
@@ -243,17 +264,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
         read_w(B, 1, FW1);
         stage(R_AH1, B ^ 1);
         cursor_advance();
+        extra_load(false);
         mem_end();
         mfma16(1, 0, FW1, first);
         mfma_end();
 
         read_a(B, 1);
         stage(R_AH0, B);
+        extra_load(true);
         mem_end();
         mfma16(1, 1, FW1, first);
         mfma_end();
 
         stage(R_WH0, B);
+        extra_load(false);
         if (last && !(DBG & 2)) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wc * 64 + nt * 16 + 4 * g);
