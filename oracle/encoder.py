@@ -7,7 +7,7 @@ Plain-torch fp32 restatement of what ``UniXcoder.forward`` computes
 key-padding masking (quirk Q2: NOT causal), erf-GELU, masked mean pooling without L2 normalisation.
 
 Pinned in this container against ``transformers.RobertaModel`` itself on seeded random weights
-(tools/gen_encoder_goldens.py -> tests/golden/encoder_*.npz).  No UniXcoder checkpoint exists offline,
+(tests/golden/gen_encoder_goldens.py -> tests/golden/encoder_*.npz).  No UniXcoder checkpoint exists offline,
 so parity with the *published weights* is unpinned; parity of the *computation* is pinned.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.

@@ -8,7 +8,7 @@ packages; the absent packages are given inert placeholder
 the module-level `import` statements succeed -- none of their behaviour is exercised except where noted.
 What is written out is DATA only: inputs fed to the reference and the outputs it returned.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_goldens.py
 """
 import asyncio
 import dataclasses
@@ -22,7 +22,7 @@ from unittest.mock import AsyncMock, MagicMock
 
 sys.dont_write_bytecode = True
 REF = Path("/root/reference/src/lattice")
-OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+OUT = Path(__file__).resolve().parent
 
 
 def shell(name, **attrs):
@@ -354,7 +354,7 @@ def main():
     R = load_reference()
     OUT.mkdir(parents=True, exist_ok=True)
     scen = ranking_scenarios(R)
-    ranking = {"generator": "tools/gen_goldens.py", "reference": "src/lattice/query/ranking/{models,scorer,ranker,utils}.py",
+    ranking = {"generator": "tests/golden/gen_goldens.py", "reference": "src/lattice/query/ranking/{models,scorer,ranker,utils}.py",
                "scenarios": [dict(s, expected=run_ranking(R, s)) for s in scen]}
     (OUT / "ranking_reference.json").write_text(json.dumps(ranking, indent=1, sort_keys=True, default=str))
     plans = {}

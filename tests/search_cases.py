@@ -1,4 +1,4 @@
-"""Seeded search cases shared by the oracle tests (CPU), the GPU parity tests and tools/gen_search_goldens.py."""
+"""Seeded search cases shared by the oracle tests (CPU), the GPU parity tests and tests/golden/gen_search_goldens.py."""
 import numpy as np
 
 D = 768

@@ -1,6 +1,6 @@
 """Callers of the hot path (providers base, Embedder, VectorIndexer, both VectorSearchers) reproduce the call
 shapes and outputs captured from the reference's own classes (tests/golden/callshapes_reference.json, made by
-tools/gen_goldens.py against AsyncMock stores/embedders).  Mirrors tests/test_embeddings.py:333-625 of the reference."""
+tests/golden/gen_goldens.py against AsyncMock stores/embedders).  Mirrors tests/test_embeddings.py:333-625 of the reference."""
 import asyncio
 import dataclasses
 import json

@@ -1,5 +1,5 @@
 """CPU tier for the encoder: the torch-fp32 oracle against fixtures produced from HF RobertaModel
-(tools/gen_encoder_goldens.py), and the host-side pieces of the HIP driver that need no GPU."""
+(tests/golden/gen_encoder_goldens.py), and the host-side pieces of the HIP driver that need no GPU."""
 import os
 
 import numpy as np

@@ -1,5 +1,5 @@
 """HybridRanker restatement against outputs captured from the reference's own ranking code
-(tests/golden/ranking_reference.json, produced by tools/gen_goldens.py)."""
+(tests/golden/ranking_reference.json, produced by tests/golden/gen_goldens.py)."""
 import dataclasses
 import json
 import os

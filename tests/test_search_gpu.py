@@ -311,3 +311,25 @@ def test_short_batches_do_not_nominate_for_padding_columns(gpu):
         assert np.array_equal(r, full_r[:nq]) and np.array_equal(s.view(np.uint32), full_s[:nq].view(np.uint32))
         assert st["fallback_used"] == 0
         assert st["candidates"] <= full["candidates"]
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_clustered_corpus_with_near_duplicate_scores(gpu, bf16):
+    """Real code embeddings cluster: 400 centres + 0.7 noise, queries near a centre, so the top-k sits inside one cluster
+    whose scores are packed within ~0.04 -- the sampled threshold must land inside the cluster and the margin logic must
+    still return the oracle's ids and bits; also with a payload filter on top."""
+    ffi = _ffi()
+    rng = np.random.default_rng(50)
+    n = 150_000
+    centres = rng.standard_normal((400, D)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    pick = rng.integers(0, 400, n)
+    x = (centres[pick] + 0.7 * rng.standard_normal((n, D)).astype(np.float32) / np.sqrt(D)).astype(np.float32)
+    q = (centres[rng.integers(0, 400, 40)] + 0.7 * rng.standard_normal((40, D)).astype(np.float32) / np.sqrt(D)).astype(np.float32)
+    codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n, n_code_cols=1)
+    idx.append(x, codes)
+    _check(idx, ffi, x, q, 100, bf16, codes=codes)
+    assert idx.stats()["fallback_used"] == 0
+    _check(idx, ffi, x, q, 100, bf16, filters=[(0, 1)], codes=codes, ofilters=[(0, 1)])
+    idx.close()

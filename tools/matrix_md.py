@@ -3,13 +3,12 @@
 import json, sys
 m = json.load(open(sys.argv[1]))
 L = ["# Measurement matrix (SURVEY §8d), one MI355X, %d x %d — `tools/bench_matrix.py`, 10 warm-up + 50 timed calls each\n" % (m["rows"], m["dim"]),
-     "| store | corpus | filter | queries/call | k | wall ms/call | device ms/call median (p10–p90) | scan kernel ms | scan GB/s | ids/scores vs oracle (200k subsample) |",
-     "|---|---|---|---|---|---|---|---|---|---|"]
+     "| store | corpus | filter | queries/call | k | wall ms/call | device ms/call median (p10–p90) | scan kernel ms | scan GB/s |",
+     "|---|---|---|---|---|---|---|---|---|"]
 for r in m["search"]:
-    d, p = r["call_ms_device"], r.get("subsample_parity")
-    par = "—" if not p else ("bit-exact / bit-exact" if p["ids_bit_exact"] and p["scores_bit_exact"] else "MISMATCH")
+    d = r["call_ms_device"]
     L.append(f"| {r['store']} | {r['corpus']} | {r['filter'] or '—'} | {r['nq']} | {r['k']} | {r['wall_ms_per_call']:.3f} | "
-             f"{d['median']:.3f} ({d['p10']:.3f}–{d['p90']:.3f}) | {r['scan_kernel_ms']:.3f} | {round(r['scan_GBps']) if r.get('scan_GBps') else '—'} | {par} |")
+             f"{d['median']:.3f} ({d['p10']:.3f}–{d['p90']:.3f}) | {r['scan_kernel_ms']:.3f} | {round(r['scan_GBps']) if r.get('scan_GBps') else '—'} |")
 L += ["", "Calls with more than 64 queries are split into 64-query passes over the corpus (4 / 16 scans).", ""]
 c = m.get("c5")
 if c and "error" not in c:
