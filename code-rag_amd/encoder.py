@@ -264,15 +264,18 @@ class HipUniXcoder:
             out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
         return out
 
-    def embed_texts(self, texts, max_length: int = 512) -> list[list[float]]:
-        """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text."""
+    def embed_texts(self, texts, max_length: int = 512, rows: str = "list"):
+        """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text.  ``rows="numpy"``
+        returns the rows as float32 numpy views instead (a list of 768-arrays): turning 768 floats per text into Python
+        floats and back into an array at the store costs as much as the GPU forward (measured 0.26 s + 0.5 s per 20 k texts)."""
         if not texts:
             return []
         if hasattr(self.tok, "encode_bodies"):
             body_ids, body_lens = self.tok.encode_bodies(list(texts), max_body=max_length - 4)
-            return self.embed_bodies(body_ids, body_lens, max_length).cpu().numpy().tolist()
-        ids = [wrap_encoder_only(self.tok, t, max_length) for t in texts]
-        return self.embed_ids(ids).cpu().numpy().tolist()
+            out = self.embed_bodies(body_ids, body_lens, max_length).cpu().numpy()
+        else:
+            out = self.embed_ids([wrap_encoder_only(self.tok, t, max_length) for t in texts]).cpu().numpy()
+        return list(out) if rows == "numpy" else out.tolist()
 
 
 _MODELS: dict = {}

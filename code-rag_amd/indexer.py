@@ -38,9 +38,9 @@ class CodeChunk:
 
     def to_payload(self) -> dict:
         """Payload stored next to the vector (chunker.py:24-37): every field, ``content`` included."""
-        p = asdict(self)
-        return {k: p[k] for k in ("file_path", "entity_type", "entity_name", "language", "start_line", "end_line",
-                                  "content", "graph_node_id", "content_hash", "project_name")}
+        return {"file_path": self.file_path, "entity_type": self.entity_type, "entity_name": self.entity_name,
+                "language": self.language, "start_line": self.start_line, "end_line": self.end_line, "content": self.content,
+                "graph_node_id": self.graph_node_id, "content_hash": self.content_hash, "project_name": self.project_name}
 
 
 _WORDISH = re.compile(r"\w+|[^\w\s]")
