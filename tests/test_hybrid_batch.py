@@ -118,3 +118,30 @@ def test_mcp_semantic_search_tool(store):
         bad = await tool["function"]("boom")
         assert bad.success is False and bad.error == "no index" and bad.data is None
     asyncio.run(go())
+
+
+def test_side_columns_host_coding():
+    """The per-row side data of the device re-rank, as coded on the host (no GPU needed until it is gathered)."""
+    import numpy as np
+    from coderag_amd.ranking.device import SideColumns, merge_key, node_key
+    payloads = [
+        {"file_path": "a.py", "entity_name": "Repo.Save", "start_line": 3, "content": "x" * 120, "graph_node_id": "pkg.Repo.Save"},
+        {"file_path": "a.py", "entity_name": "Repo.Save", "start_line": 3, "content": None},                       # same merge key, no node id
+        {"file_path": "b.py", "entity_name": "", "start_line": None, "content": ""},
+        None,                                                                                                       # tombstoned row
+        {"file_path": "b.py", "entity_name": "Löwe" + "x" * 70, "start_line": 1, "content": "y", "graph_node_id": "pkg.Repo.Save"},
+    ]
+    side = SideColumns(0)
+    side.append(payloads[:2])
+    side.append(payloads[2:])
+    h = side._host
+    assert side.rows == 5 and h["content_len"] == [120, 0, 0, 0, 1]
+    assert h["key_code"][0] == h["key_code"][1] != h["key_code"][2]
+    assert h["file_code"][0] == h["file_code"][1] and h["file_code"][2] == h["file_code"][4]
+    assert h["node_code"][0] == h["node_code"][4] != h["node_code"][1]            # graph_node_id wins over entity_name
+    assert h["name_len"] == [9, 9, 0, 0, len(("löwe" + "x" * 70).encode())]
+    assert side._names[0].rstrip(b"\x00") == b"repo.save" and len(side._names[4]) == 64                              # lower-cased, cut to 64 bytes
+    assert h["degree"] == [-1] * 5
+    side.set_degrees({"pkg.Repo.Save": 12, "Repo.Save": 3})
+    assert side._host["degree"] == [12, 3, -1, -1, 12]
+    assert node_key(payloads[1]) == "Repo.Save" and merge_key(payloads[2]) == "b.py::None"
