@@ -712,6 +712,90 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
     sent[(size_t)b * D + d] = acc / (float)cnt;  // an all-pad row divides 0/0 exactly like the reference's mean
 }
 
+// ------------------------------------------------------------------ skinny GEMM (T <= 256: the query path)
+//
+// One short query is 32-64 tokens: the tiled kernels above would run one 256-row tile per column block with a handful of
+// rows in it, ~15 us per call, 48 calls per forward.  Here a workgroup owns 16 output columns and a slab of <= 64 rows; its four
+// waves split K, every lane fetches its MFMA operand pieces straight from global memory (16 bytes of one W row / one A
+// row per k-step of 32: no LDS staging, the whole W matrix is read exactly once across the grid), the four partial
+// accumulators meet in LDS and wave w finishes 16-row block w.  C^T fragments as everywhere: a lane ends up with 4
+// consecutive n of one row m.  N % 16 == 0, K % 128 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ C, int M, int N, int K)
+{
+    __shared__ f32x4 part[4][4][64];   // [wave][m-block][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    // blockIdx.y selects a slab of 64 rows (T <= 256: up to four slabs, each re-reading W)
+    const int row0 = blockIdx.y * 64;
+    A += (size_t)row0 * K;
+    C += (size_t)row0 * N;
+    if (EPI == 2) R += (size_t)row0 * N;
+    M = (M - row0) < 64 ? (M - row0) : 64;
+    const int MB = (M + 15) >> 4;      // 1..4
+    const int kspan = K >> 2, k0 = wave * kspan;
+    const bf16_t *wp = W + (size_t)(n0 + r16) * K + k0 + kq * 8;
+    const bf16_t *ap[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        int m = mb * 16 + r16;
+        m = m < M ? m : M - 1;          // rows past M: a valid row, result never stored
+        ap[mb] = A + (size_t)m * K + k0 + kq * 8;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < kspan; s0 += 192) {      // 6 k-steps of 32 per round (K = 768: one round per wave)
+        bf16x8 wf[6], af[4][6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const bool on = s0 + s * 32 < kspan;
+            wf[s] = on ? *reinterpret_cast<const bf16x8 *>(wp + s0 + s * 32) : bf16x8{};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                af[mb][s] = (on && mb < MB) ? *reinterpret_cast<const bf16x8 *>(ap[mb] + s0 + s * 32) : bf16x8{};
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+                if (mb < MB) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[mb][s], acc[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) part[wave][mb][lane] = acc[mb];
+    __syncthreads();
+    if (wave >= MB) return;
+    const int mb = wave;
+    f32x4 v = part[0][mb][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += part[w][mb][lane];
+    // v[j] = C[mb*16 + r16][n0 + 4*kq + j]
+    const int m = mb * 16 + r16, n = n0 + 4 * kq;
+    const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
+    float o0 = v[0] + b4.x, o1 = v[1] + b4.y, o2 = v[2] + b4.z, o3 = v[3] + b4.w;
+    if (EPI == 1) {
+        const f32x2_t ga = gelu_erf2(f32x2_t{o0, o1}), gb = gelu_erf2(f32x2_t{o2, o3});
+        o0 = ga.x;
+        o1 = ga.y;
+        o2 = gb.x;
+        o3 = gb.y;
+    }
+    if (m >= M) return;
+    if (EPI == 2) {
+        const u32x2 r2 = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
+        o0 += bf2f(r2.x & 0xffffu);
+        o1 += bf2f(r2.x >> 16);
+        o2 += bf2f(r2.y & 0xffffu);
+        o3 += bf2f(r2.y >> 16);
+    }
+    u32x2 o;
+    o.x = pack2(o0, o1);
+    o.y = pack2(o2, o3);
+    *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
+}
+
 #include "crh_gemm256.hpp"
 
 }  // namespace enc
@@ -750,6 +834,16 @@ int gemm256_mode()
         mode = e ? atoi(e) : 1;
     }
     return mode;
+}
+// T <= 256 rows (one query, a few short ones): k_gemm_skinny; CODERAG_HIP_SKINNY=0 keeps the tiled kernel
+bool use_skinny(int T, int N, int K)
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("CODERAG_HIP_SKINNY");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on && T <= 256 && N % 16 == 0 && K % 128 == 0;
 }
 bool use_gemm256(int T, int N, int K)
 {
@@ -817,6 +911,14 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
     if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
     if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm: act=%d (0 none, 1 gelu)", act);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_skinny(T, N, K)) {
+        if (act == 1)
+            hipLaunchKernelGGL((k_gemm_skinny<1>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<0>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     if (use_gemm256(T, N, K)) return launch_gemm256(act, x, w, bias, nullptr, y, T, N, K, st);
     const dim3 grid(gemm_grid(T, N));
     CRH_TRY(gemm_lds_attr());
@@ -892,6 +994,13 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
     if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_skinny(T, N, K) && y != residual) {
+        hipLaunchKernelGGL((k_gemm_skinny<2>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)residual, (bf16_t *)y, T, N, K);
+        CRH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     if (use_gemm256(T, N, K) && K <= 1024 && y != residual) {
         // short K: the residual joins in the LayerNorm kernel instead of the GEMM epilogue (see k_layernorm768_res)
         CRH_TRY(launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st));

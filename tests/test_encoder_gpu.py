@@ -24,7 +24,9 @@ def _close(torch, got, ref, rel, abs_):
 
 
 # T >= 3841 rows exercises the per-XCD super-tile order (>= 16 panels), smaller T the linear order; ragged T the row guards
-@pytest.mark.parametrize("T,N,K,act", [(384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0),
+# T <= 256 goes to the skinny kernel (k_gemm_skinny: the query path)
+@pytest.mark.parametrize("T,N,K,act", [(1, 768, 768, 0), (17, 2304, 768, 0), (64, 3072, 768, 1), (33, 768, 3072, 0), (48, 768, 256, 1), (65, 2304, 768, 0), (200, 3072, 768, 1), (256, 768, 3072, 0),
+                                       (384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0),
                                        (5000, 2304, 768, 0), (9300, 3072, 768, 1), (4097, 768, 3072, 0)])
 def test_gemm_bias_act(gpu, T, N, K, act):
     torch, ffi, dev = _env()
@@ -84,7 +86,7 @@ def test_gemm256_repeatable(gpu):
         assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
 
 
-@pytest.mark.parametrize("T,K", [(256, 768), (100, 3072), (6000, 768), (22100, 3072), (23040, 768)])
+@pytest.mark.parametrize("T,K", [(1, 768), (40, 3072), (64, 768), (129, 3072), (256, 768), (257, 768), (300, 3072), (6000, 768), (22100, 3072), (23040, 768)])
 def test_gemm_residual_layernorm(gpu, T, K):
     torch, ffi, dev = _env()
     g = torch.Generator(device="cpu").manual_seed(K)
@@ -219,7 +221,9 @@ def test_provider_end_to_end(gpu):
         return one, many
     one, many = asyncio.run(go())
     assert p.embedding_dim == 768 and len(one) == 768 and isinstance(one[0], float) and len(many) == 4
-    assert np.allclose(many[0], many[3], atol=0, rtol=0)                 # same text, same vector (different batch slots)
+    # same text in different batches: the GEMM kernel is chosen by the batch's token count (<= 64 rows: the split-K skinny
+    # kernel) and the kernels differ in f32 summation order, so equality holds to bf16 accuracy, not to the bit
+    assert np.abs(np.asarray(many[0]) - np.asarray(many[3])).max() <= 2e-2 * np.abs(np.asarray(one)).max()
     assert np.abs(np.asarray(one) - np.asarray(many[0])).max() <= 2e-2 * np.abs(np.asarray(one)).max()
     assert not np.allclose(many[0], many[1], atol=1e-3)
 
