@@ -13,13 +13,14 @@ rng = np.random.default_rng(1)
 for B, L in ((1, 16), (1, 32), (1, 64), (1, 128), (1, 256), (1, 512), (8, 32)):
     ids = rng.integers(16, cfg.vocab_size, (B, L)).astype(np.int32)
     t = torch.from_numpy(ids).to(dev)
-    for _ in range(5):
-        model.forward_ids(t)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(50):
-        t0 = time.perf_counter()
-        model.forward_ids(t)
+    for name, fn in (("forward", model.forward_ids),):
+        for _ in range(5):
+            fn(t)
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"B={B} L={L}: median {np.median(ts):.3f} ms  p90 {np.percentile(ts, 90):.3f}", flush=True)
+        ts = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            fn(t)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print(f"B={B} L={L} {name}: median {np.median(ts):.3f} ms  p90 {np.percentile(ts, 90):.3f}", flush=True)
