@@ -173,3 +173,31 @@ def test_store_search_and_rank_on_device_equals_host_path(gpu):
                [(r.file_path, r.entity_name, r.start_line, r.final_score, r.source) for r in w]
         assert [[r.signal_scores[s] for s in SIGNALS] for r in g] == [[r.signal_scores[s] for s in SIGNALS] for r in w]
         assert [r.content for r in g] == [r.content for r in w]
+
+
+def test_sharded_index_rerank_single_rank(gpu):
+    """ShardedIndex.search_rerank (world size 1 here; the N>1 column exchange is covered under gloo) equals scan + gather +
+    DeviceReranker done by hand, and survives deletes / re-upserts of rows that already have side columns."""
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd.ranking.device import DeviceReranker, SideColumns
+    from coderag_amd.sharded import ShardedIndex
+    rng = random.Random(21)
+    n, nq, k = 2000, 8, 50
+    payloads = _payloads(n, rng)
+    vecs = np.random.default_rng(2).standard_normal((n, 768)).astype(np.float32)
+    sh = ShardedIndex(768, shard_capacity=4096, device=0)
+    sh.append_local(vecs)
+    side = SideColumns(0)
+    side.append(payloads)
+    sh.attach_side_columns(side)
+    sh.index.tombstone(np.arange(0, n, 7))                     # deleted rows keep their (now unused) side data
+    q = vecs[:nq] + 0.3 * np.random.default_rng(3).standard_normal((nq, 768)).astype(np.float32)
+    plans = [NS(primary_intent=rng.choice(INTENTS), entities=[NS(name=rng.choice(VOCAB[:7]))]) for _ in range(nq)]
+    rr = DeviceReranker()
+    out, s, r = sh.search_rerank(q, k, plans, rr)
+    assert not np.isin(r.cpu().numpy(), np.arange(0, n, 7)).any()
+    ref = rr.rank(s, r, side.gather(r), plans)
+    assert np.array_equal(out.count, ref.count) and np.array_equal(out.index, ref.index) and np.array_equal(out.score, ref.score)
+    assert (out.count > 0).all()
+    sh.close()
