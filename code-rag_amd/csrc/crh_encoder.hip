@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
     sent[(size_t)b * D + d] = acc / (float)cnt;  // an all-pad row divides 0/0 exactly like the reference's mean
 }
 
-// ------------------------------------------------------------------ skinny GEMM (T <= 256: the query path)
+// ------------------------------------------------------------------ skinny GEMM (T <= 512: the query path)
 //
 // One short query is 32-64 tokens: the tiled kernels above would run one 256-row tile per column block with a handful of
 // rows in it, ~15 us per call, 48 calls per forward.  Here a workgroup owns 16 output columns and a slab of <= 64 rows; its four
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    // blockIdx.y selects a slab of 64 rows (T <= 256: up to four slabs, each re-reading W)
+    // blockIdx.y selects a slab of 64 rows (T <= 512: up to eight slabs, each re-reading W)
     const int row0 = blockIdx.y * 64;
     A += (size_t)row0 * K;
     C += (size_t)row0 * N;
@@ -835,7 +835,7 @@ int gemm256_mode()
     }
     return mode;
 }
-// T <= 256 rows (one query, a few short ones): k_gemm_skinny; CODERAG_HIP_SKINNY=0 keeps the tiled kernel
+// T <= 512 rows (one query, a few short ones): k_gemm_skinny; CODERAG_HIP_SKINNY=0 keeps the tiled kernel
 bool use_skinny(int T, int N, int K)
 {
     static int on = -1;
@@ -843,7 +843,12 @@ bool use_skinny(int T, int N, int K)
         const char *e = getenv("CODERAG_HIP_SKINNY");
         on = (e && e[0] == '0') ? 0 : 1;
     }
-    return on && T <= 256 && N % 16 == 0 && K % 128 == 0;
+    static int tmax = 0;
+    if (!tmax) {
+        const char *e = getenv("CODERAG_HIP_SKINNY_MAX_T");
+        tmax = e ? atoi(e) : 512;   // measured crossover against the tiled kernel (tools/latency_bench.py)
+    }
+    return on && T <= tmax && N % 16 == 0 && K % 128 == 0;
 }
 bool use_gemm256(int T, int N, int K)
 {

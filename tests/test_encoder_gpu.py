@@ -24,9 +24,9 @@ def _close(torch, got, ref, rel, abs_):
 
 
 # T >= 3841 rows exercises the per-XCD super-tile order (>= 16 panels), smaller T the linear order; ragged T the row guards
-# T <= 256 goes to the skinny kernel (k_gemm_skinny: the query path)
-@pytest.mark.parametrize("T,N,K,act", [(1, 768, 768, 0), (17, 2304, 768, 0), (64, 3072, 768, 1), (33, 768, 3072, 0), (48, 768, 256, 1), (65, 2304, 768, 0), (200, 3072, 768, 1), (256, 768, 3072, 0),
-                                       (384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0),
+# T <= 512 goes to the skinny kernel (k_gemm_skinny: the query path)
+@pytest.mark.parametrize("T,N,K,act", [(1, 768, 768, 0), (17, 2304, 768, 0), (64, 3072, 768, 1), (33, 768, 3072, 0), (48, 768, 256, 1), (65, 2304, 768, 0), (200, 3072, 768, 1), (256, 768, 3072, 0), (500, 2304, 768, 0), (513, 768, 768, 0),
+                                       (384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0), (500, 2304, 768, 0), (513, 768, 768, 0),
                                        (5000, 2304, 768, 0), (9300, 3072, 768, 1), (4097, 768, 3072, 0)])
 def test_gemm_bias_act(gpu, T, N, K, act):
     torch, ffi, dev = _env()

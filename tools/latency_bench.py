@@ -10,7 +10,7 @@ cfg = drv.EncoderConfig()
 model = drv.HipUniXcoder(drv.synthetic_weights(cfg, 23), cfg, drv.HashTokenizer(cfg.vocab_size), 0)
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(1)
-for B, L in ((1, 16), (1, 32), (1, 64), (1, 128), (1, 256), (1, 512), (8, 32)):
+for B, L in ((1, 16), (1, 64), (1, 256), (1, 384), (1, 512), (8, 64), (16, 64), (32, 64), (4, 512)):
     ids = rng.integers(16, cfg.vocab_size, (B, L)).astype(np.int32)
     t = torch.from_numpy(ids).to(dev)
     for name, fn in (("forward", model.forward_ids),):
