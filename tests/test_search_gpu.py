@@ -333,3 +333,44 @@ def test_clustered_corpus_with_near_duplicate_scores(gpu, bf16):
     assert idx.stats()["fallback_used"] == 0
     _check(idx, ffi, x, q, 100, bf16, filters=[(0, 1)], codes=codes, ofilters=[(0, 1)])
     idx.close()
+
+
+def test_randomised_configurations_against_the_oracle(gpu):
+    """40 seeded random configurations -- width, store precision, row count (down to 1), query count (across the 64-query
+    pass boundary), k (beyond the row count too), tombstones, a payload filter, duplicated rows (exact ties), zero rows,
+    a non-zero row_base, appends in several pieces -- each compared bit for bit with the oracle."""
+    ffi = _ffi()
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        dim = int(rng.choice([384, 768, 768, 768, 1024, 1536]))
+        bf16 = bool(rng.integers(0, 2))
+        n = int(rng.choice([1, 2, 31, 32, 33, 100, 1000, 4097, int(rng.integers(5000, 30000))]))
+        nq = int(rng.choice([1, 2, 31, 64, 65, 100, 130]))
+        k = int(rng.choice([1, 5, 10, 100, 257]))
+        x = rng.standard_normal((n, dim), dtype=np.float32) * rng.uniform(0.2, 5.0, size=(n, 1)).astype(np.float32)
+        if n > 10:
+            dup = rng.integers(0, n, max(1, n // 20))
+            x[dup] = x[rng.integers(0, n, len(dup))]                   # exact duplicates -> exact score ties
+            x[rng.integers(0, n, 2)] = 0.0                             # zero rows stay zero (score 0)
+        q = rng.standard_normal((nq, dim), dtype=np.float32)
+        if nq > 1 and n > 1:
+            q[0] = x[int(rng.integers(0, n))] * 3.0                     # a query that IS a stored row
+        ncols = int(rng.integers(0, 3))
+        codes = rng.integers(0, 4, (n, ncols)).astype(np.int32) if ncols else None
+        idx = ffi.Index(dim, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=max(64, n), n_code_cols=ncols)
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, 2)]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                idx.append(x[a:b], codes[a:b] if ncols else None)
+        alive = np.ones(n, dtype=bool)
+        if n > 3 and rng.random() < 0.6:
+            dead = rng.integers(0, n, int(n * rng.uniform(0.01, 0.3)) + 1)
+            idx.tombstone(dead)
+            alive[dead] = False
+        filt = [(0, int(rng.integers(0, 4)))] if ncols and rng.random() < 0.6 else None
+        base = int(rng.choice([0, 0, 1 << 20, 7_000_000_000]))
+        try:
+            _check(idx, ffi, x, q, k, bf16, filters=filt, alive=alive, codes=codes, ofilters=filt, row_base=base)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: dim={dim} bf16={bf16} n={n} nq={nq} k={k} ncols={ncols} filt={filt} base={base}: {e}")
+        idx.close()
