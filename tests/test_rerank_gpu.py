@@ -201,3 +201,30 @@ def test_sharded_index_rerank_single_rank(gpu):
     assert np.array_equal(out.count, ref.count) and np.array_equal(out.index, ref.index) and np.array_equal(out.score, ref.score)
     assert (out.count > 0).all()
     sh.close()
+
+
+def test_rerank_on_empty_and_tiny_collections(gpu):
+    """No rows at all, fewer rows than the limit, and a filter that matches nothing: empty ranked lists, no error."""
+    import asyncio
+    import uuid
+    import coderag_amd  # noqa: F401
+    from coderag_amd.engine_helpers import search_and_rank_batch_device
+    from coderag_amd.ranking import HybridRanker
+    from coderag_amd.ranking.device import DeviceReranker
+    from coderag_amd.store import CollectionName, HipVectorStore
+    qv = np.random.default_rng(1).standard_normal((3, 768)).astype(np.float32)
+    plans = [NS(primary_intent="unknown", entities=[NS(name="x")]) for _ in range(3)]
+
+    async def run():
+        out = []
+        async with HipVectorStore(dim=768, initial_capacity=64) as store:
+            await store.create_collections()
+            out.append(await search_and_rank_batch_device(store, DeviceReranker(), HybridRanker(), qv, plans, limit=20))
+            pay = [{"file_path": "a.py", "entity_name": f"f{i}", "start_line": i, "content": "x" * 150, "language": "python"} for i in range(3)]
+            await store.upsert(CollectionName.CODE_CHUNKS.value, [str(uuid.UUID(int=i)) for i in range(3)], qv, pay)
+            out.append(await search_and_rank_batch_device(store, DeviceReranker(), HybridRanker(), qv, plans, limit=20))
+            out.append(await search_and_rank_batch_device(store, DeviceReranker(), HybridRanker(), qv, plans, limit=20, language="rust"))
+        return out
+    empty, tiny, filtered = asyncio.run(run())
+    assert [len(r) for r in empty] == [0, 0, 0] and [len(r) for r in filtered] == [0, 0, 0]
+    assert [len(r) for r in tiny] == [3, 3, 3] and all(r[0].entity_name == f"f{i}" for i, r in enumerate(tiny))
