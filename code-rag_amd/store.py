@@ -14,6 +14,7 @@ There is no CPU fallback: without the native library or a gfx950 device ``connec
 from __future__ import annotations
 
 import asyncio
+import os
 import logging
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -263,7 +264,7 @@ class HipVectorStore:
 
     def __init__(self, host: str | None = None, port: int | None = None, grpc_port: int | None = None, *,
                  device: int | None = None, dim: int | None = None, dtype: str | None = None,
-                 initial_capacity: int | None = None):
+                 initial_capacity: int | None = None, search_window_ms: float | None = None):
         s = get_settings()
         self._host, self._port, self._grpc_port = host, port, grpc_port
         self._device = s.hip_device if device is None else device
@@ -281,6 +282,15 @@ class HipVectorStore:
         self._client: _RawClient | None = None
         self._executor: ThreadPoolExecutor | None = None
         self._lock = threading.Lock()
+        # Concurrent search() calls (many users, one query each -- how the reference's query path arrives) are coalesced: what
+        # comes in within this window, for the same collection and filter, shares ONE pass over the corpus (up to 64 queries
+        # cost what one costs).  0 disables it; CODERAG_HIP_SEARCH_WINDOW_MS overrides the default.
+        if search_window_ms is None:
+            search_window_ms = float(os.environ.get("CODERAG_HIP_SEARCH_WINDOW_MS", "0.3"))
+        self._search_window_s = max(0.0, search_window_ms) / 1e3
+        self._search_pending: dict[tuple, list] = {}
+        self._search_drainers: dict[tuple, asyncio.Task] = {}
+        self.search_passes = 0                      # corpus passes issued by search() (observability / tests)
 
     # ------------------------------------------------------------------ plumbing
     async def _run(self, fn, *args):
@@ -413,14 +423,55 @@ class HipVectorStore:
                     rows = [] if dfilt is None else col.index.match_rows(dfilt, limit)
                     return [col.hit(int(r), 0.0) for r in rows]
                 results = await self._run(fetch)
+            elif len(query_vector) != self._col(collection).index.dim:   # (must not fail the pass it would have joined)
+                raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).index.dim}")
+            elif self._search_window_s > 0:
+                results = await self._search_coalesced(collection, query_vector, limit, filters)
             else:
                 q = np.asarray(query_vector, dtype=np.float32).reshape(1, -1)
+                self.search_passes += 1
                 col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
                 results = [col.hit(int(r), float(s)) for s, r in zip(scores[0], rows[0]) if r >= 0]
             logger.debug(f"Found {len(results)} results in {collection}")
             return results
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)
+
+    async def _search_coalesced(self, collection: str, query_vector, limit: int, filters: dict[str, Any] | None):
+        """One entry of a coalesced pass: queue the query, let the key's drainer run the batch, return this call's slice.
+        Calls are grouped by (collection, filter); the pass asks for the largest limit of the group and each caller keeps
+        its own prefix (an exact top-k list is a prefix of every longer one)."""
+        loop = asyncio.get_running_loop()
+        name = collection.value if isinstance(collection, CollectionName) else collection
+        key = (name, tuple(sorted((k, _hashable(v)) for k, v in (filters or {}).items())))
+        vec = np.asarray(query_vector, dtype=np.float32).reshape(-1)
+        fut: asyncio.Future = loop.create_future()
+        self._search_pending.setdefault(key, []).append((vec, int(limit), fut))
+        task = self._search_drainers.get(key)
+        if task is None or task.done():
+            self._search_drainers[key] = loop.create_task(self._drain_searches(key, name, filters))
+        return await fut
+
+    async def _drain_searches(self, key, name: str, filters) -> None:
+        while self._search_pending.get(key):
+            await asyncio.sleep(self._search_window_s)
+            batch = self._search_pending.pop(key, [])
+            if not batch:
+                break
+            for start in range(0, len(batch), 256):
+                part = batch[start:start + 256]
+                try:
+                    q = np.stack([b[0] for b in part])
+                    kmax = max(b[1] for b in part)
+                    self.search_passes += (len(part) + 63) // 64
+                    col, scores, rows = await self._run(self._search_sync, name, q, kmax, filters)
+                    for (_, lim, fut), srow, rrow in zip(part, scores, rows):
+                        if not fut.done():
+                            fut.set_result([col.hit(int(r), float(s)) for s, r in zip(srow[:max(lim, 0)], rrow[:max(lim, 0)]) if r >= 0])
+                except Exception as e:  # noqa: BLE001 -- every caller of the pass sees the failure (wrapped by search())
+                    for _, _, fut in part:
+                        if not fut.done():
+                            fut.set_exception(e)
 
     async def search_batch(self, collection: str, query_vectors, limit: int = 10,
                            filters: dict[str, Any] | None = None) -> list[list[dict[str, Any]]]:

@@ -57,3 +57,31 @@ def test_dimension_defaults_follow_provider(monkeypatch):
     assert store_mod.HipVectorStore()._dimensions == 1536         # quirk Q3 reproduced unless dim= is passed
     assert store_mod.QdrantManager is store_mod.HipVectorStore
     assert [c.value for c in store_mod.CollectionName] == ["code_chunks", "summaries"]
+
+
+def test_concurrent_searches_share_corpus_passes(fake):
+    """Many callers, one query each (how the reference's query path arrives): what lands within the window, for the same
+    collection and filter, is served by one pass; every caller gets exactly what a lone call returns (its own limit, its
+    own filter), and a malformed query fails alone."""
+    import uuid
+    rng = np.random.default_rng(4)
+    n = 500
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    pay = [{"file_path": f"f{i % 7}.py", "entity_name": f"e{i}", "language": ("python", "go")[i % 2], "content": "x"} for i in range(n)]
+    qs = rng.standard_normal((90, 768)).astype(np.float32)
+    limits = [int(rng.integers(1, 30)) for _ in range(90)]
+    filts = [None if i % 3 else {"language": "go"} for i in range(90)]
+
+    async def go(window_ms):
+        async with store_mod.HipVectorStore(dim=768, initial_capacity=1024, search_window_ms=window_ms) as s:
+            await s.create_collections()
+            await s.upsert("code_chunks", [str(uuid.UUID(int=i)) for i in range(n)], vecs, pay)
+            res = await asyncio.gather(*(s.search("code_chunks", qs[i].tolist(), limit=limits[i], filters=filts[i]) for i in range(90)))
+            with pytest.raises(VectorStoreError):
+                await s.search("code_chunks", [0.0] * 10, limit=3)
+            return res, s.search_passes
+    lone, passes_lone = asyncio.run(go(0))
+    together, passes_together = asyncio.run(go(5.0))
+    assert passes_lone == 90 and passes_together <= 4
+    assert [[(h["id"], h["score"]) for h in r] for r in together] == [[(h["id"], h["score"]) for h in r] for r in lone]
+    assert all(len(r) == min(limits[i], n if filts[i] is None else n // 2) for i, r in enumerate(together))
