@@ -282,11 +282,13 @@ class HipVectorStore:
         self._client: _RawClient | None = None
         self._executor: ThreadPoolExecutor | None = None
         self._lock = threading.Lock()
-        # Concurrent search() calls (many users, one query each -- how the reference's query path arrives) are coalesced: what
-        # comes in within this window, for the same collection and filter, shares ONE pass over the corpus (up to 64 queries
-        # cost what one costs).  0 disables it; CODERAG_HIP_SEARCH_WINDOW_MS overrides the default.
+        # Concurrent search() calls (many users, one query each -- how the reference's query path arrives) are coalesced: the
+        # calls that queue up while a pass over the corpus is running, for the same collection and filter, share the NEXT pass
+        # (up to 64 queries cost what one costs); an idle store serves a lone call at once.  search_window_ms > 0 additionally
+        # waits that long before each pass; < 0 (or CODERAG_HIP_SEARCH_WINDOW_MS=-1) turns coalescing off.
         if search_window_ms is None:
-            search_window_ms = float(os.environ.get("CODERAG_HIP_SEARCH_WINDOW_MS", "0.3"))
+            search_window_ms = float(os.environ.get("CODERAG_HIP_SEARCH_WINDOW_MS", "0"))
+        self._search_coalesce = search_window_ms >= 0
         self._search_window_s = max(0.0, search_window_ms) / 1e3
         self._search_pending: dict[tuple, list] = {}
         self._search_drainers: dict[tuple, asyncio.Task] = {}
@@ -425,7 +427,7 @@ class HipVectorStore:
                 results = await self._run(fetch)
             elif len(query_vector) != self._col(collection).index.dim:   # (must not fail the pass it would have joined)
                 raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).index.dim}")
-            elif self._search_window_s > 0:
+            elif self._search_coalesce:
                 results = await self._search_coalesced(collection, query_vector, limit, filters)
             else:
                 q = np.asarray(query_vector, dtype=np.float32).reshape(1, -1)
@@ -454,7 +456,7 @@ class HipVectorStore:
 
     async def _drain_searches(self, key, name: str, filters) -> None:
         while self._search_pending.get(key):
-            await asyncio.sleep(self._search_window_s)
+            await asyncio.sleep(self._search_window_s)       # (0: one turn of the loop, so calls issued together travel together)
             batch = self._search_pending.pop(key, [])
             if not batch:
                 break

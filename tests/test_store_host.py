@@ -80,8 +80,8 @@ def test_concurrent_searches_share_corpus_passes(fake):
             with pytest.raises(VectorStoreError):
                 await s.search("code_chunks", [0.0] * 10, limit=3)
             return res, s.search_passes
-    lone, passes_lone = asyncio.run(go(0))
-    together, passes_together = asyncio.run(go(5.0))
+    lone, passes_lone = asyncio.run(go(-1))
+    together, passes_together = asyncio.run(go(0))
     assert passes_lone == 90 and passes_together <= 4
     assert [[(h["id"], h["score"]) for h in r] for r in together] == [[(h["id"], h["score"]) for h in r] for r in lone]
     assert all(len(r) == min(limits[i], n if filts[i] is None else n // 2) for i, r in enumerate(together))

@@ -12,7 +12,7 @@ rng = np.random.default_rng(0)
 
 
 async def main():
-    for window in (0.0, 0.3, 1.0):
+    for window in (-1.0, 0.0, 0.3):
         async with HipVectorStore(dim=768, dtype="bf16", initial_capacity=rows, search_window_ms=window) as s:
             await s.create_collections()
             for r0 in range(0, rows, 100_000):
