@@ -130,7 +130,9 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
         # files at a time under a semaphore of 5 (pipeline/orchestrator.py:652-656, providers/base.py:148) -- are coalesced
         # into ONE length-bucketed GPU submission instead of queueing behind each other on the single worker thread
         self.dynamic_batching = bool(config.extra.get("dynamic_batching", True))
-        self.batch_window_s = float(config.extra.get("batch_window_ms", 2.0)) / 1e3
+        # window 0 (default): no timer -- the calls that queue up while a submission is on the GPU travel in the next one, and an
+        # idle provider embeds a lone call (a query) at once; > 0 additionally waits that long before each submission
+        self.batch_window_s = float(config.extra.get("batch_window_ms", 0.0)) / 1e3
         self.max_batch_texts = int(config.extra.get("max_batch_texts", 4096))
         # "list" (default): list[list[float]] exactly as the reference's providers return; "numpy": list of float32 arrays --
         # what a store that converts to an array anyway (Qdrant's client does, HipVectorStore does) takes several times faster
