@@ -213,12 +213,14 @@ def main() -> None:
         "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "bf16 corpus/query, f32 accumulate" if args.dtype == "bf16" else "f32 store (bf16 scan + f32 canonical re-score)",
+        "dtype": "bf16" if args.dtype == "bf16" else "f32",
         "data": "synthetic: N(0,I) rows generated on device (torch seed 20251226+rank), normalised on insert; queries numpy default_rng(7)",
         "config": {"workload": f"{world}x MI355X: {N}x{D} {args.dtype} corpus per GPU resident in HBM, batch-{B} queries, exact top-{K}"
                                + (", all-gather + merge of per-GPU top-k over RCCL" if world > 1 else "")
                                + (f" ({args.rows} rows in total, strong scaling)" if args.scaling == "strong" else ""),
-                   "rows_per_gpu": N, "dim": D, "batch": B, "k": K, "parallelism": f"row-shard x{world}"},
+                   "rows_per_gpu": N, "dim": D, "batch": B, "k": K, "parallelism": f"row-shard x{world}",
+                   "precision": ("bf16 corpus and queries on MFMA, f32 accumulate, canonical f32 re-score of the survivors" if args.dtype == "bf16"
+                                 else "f32 store: bf16 MFMA scan nominates, f32 canonical re-score decides")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None,
