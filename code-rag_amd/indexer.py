@@ -53,9 +53,14 @@ class CodeChunker:
     chunk boundaries are identical.  Without it (this image) a word/punctuation count stands in -- a NEXT row
     of SURVEY.md section 8f, not part of the measured hot path."""
 
-    def __init__(self, max_tokens: int | None = None, overlap_tokens: int | None = None, encoding_name: str = "cl100k_base"):
+    def __init__(self, max_tokens: int | None = None, overlap_tokens: int | None = None, encoding_name: str = "cl100k_base",
+                 *, encode: Callable[[str], list] | None = None):
+        # both fall back on a falsy value, so overlap_tokens=0 means "the configured default" (chunker.py:47-49)
         self.max_tokens = max_tokens or 1000
-        self.overlap_tokens = overlap_tokens if overlap_tokens is not None else 200
+        self.overlap_tokens = overlap_tokens or 200
+        if encode is not None:              # an explicit token counter (tests pin the algorithm with the goldens' one)
+            self._encode = encode
+            return
         try:
             import tiktoken
             self._encode = tiktoken.get_encoding(encoding_name).encode
@@ -71,8 +76,8 @@ class CodeChunker:
         common = dict(file_path=file_path, language=language, content_hash=info.content_hash, project_name=project_name)
         chunks: list[CodeChunk] = []
         for entity in parsed_file.all_entities:
-            text = "\n".join(part for part in (entity.signature, f'"""{entity.docstring}"""' if entity.docstring else None,
-                                                entity.code) if part)
+            head = [part for part in (entity.signature, f'"""{entity.docstring}"""' if entity.docstring else None) if part]
+            text = "\n".join(head + [entity.code])          # the code is always appended, even when empty (chunker.py:127-134)
             etype = getattr(entity.type, "value", entity.type)
             if self.count_tokens(text) <= self.max_tokens:
                 chunks.append(CodeChunk(content=text, entity_type=etype, entity_name=entity.qualified_name,

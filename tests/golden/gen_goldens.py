@@ -349,6 +349,93 @@ async def run_callshapes(R):
     out["a12_query_searcher"] = a12
     return out
 
+# ---------------------------------------------------------------------------------------------- chunking
+def chunker_scenarios():
+    """Parsed files (as plain dicts) x chunker parameters.  The token counter is the stand-in installed above
+    (whitespace split): tiktoken's cl100k table is not in the image, so the goldens pin the chunking ALGORITHM
+    (entity formatting, line packing, overlap carry, naming, line numbers), with the counter as an input."""
+    import random
+    rng = random.Random(20260104)
+    words = ["alpha", "beta", "gamma", "delta", "x", "=", "return", "self.value", "(", ")", "if", "else:", "for", "in", "range(10):"]
+
+    def body(n_lines, lo=1, hi=9, blank_every=0):
+        lines = []
+        for i in range(n_lines):
+            if blank_every and i % blank_every == blank_every - 1:
+                lines.append("")
+            else:
+                lines.append("    " + " ".join(rng.choice(words) for _ in range(rng.randint(lo, hi))))
+        return "\n".join(lines)
+
+    def ent(name, code, etype="function", sig=None, doc=None, start=1, children=(), qn=None):
+        return dict(type=etype, name=name, qualified_name=qn or f"pkg.mod.{name}", signature=sig, docstring=doc, code=code,
+                    start_line=start, end_line=start + code.count("\n"), children=list(children))
+
+    def pfile(path, content, entities, language="python"):
+        return dict(path=path, language=language, content_hash=f"h-{len(content)}", content=content, entities=entities)
+
+    big = body(120, blank_every=7)
+    huge_line = "    " + " ".join("tok%d" % i for i in range(90))
+    files = {
+        "small_entities": pfile("src/app/small.py", "irrelevant", [
+            ent("load", body(4), sig="def load(path):", doc="Load a file.", start=3),
+            ent("Repo", body(6), etype="class", sig="class Repo:", start=20,
+                children=[ent("get", body(3), etype="method", sig="def get(self, k):", start=22, qn="pkg.mod.Repo.get"),
+                          ent("put", body(5), etype="method", sig=None, doc="Store.", start=27, qn="pkg.mod.Repo.put")]),
+        ]),
+        "one_large_entity": pfile("src/app/large.py", "irrelevant", [ent("pipeline", big, sig="def pipeline(cfg):", doc="Run it.", start=40)]),
+        "mixed": pfile("src/app/mixed.ts", "irrelevant", [
+            ent("tiny", "    return 1", sig="function tiny()", start=1),
+            ent("wide", body(60, lo=6, hi=12), sig="function wide(a, b)", start=10),
+            ent("empty_code", "", sig="function empty_code()", start=90),
+            ent("doc_only", body(2), sig=None, doc="Only a docstring\nover two lines.", start=95),
+        ], language="typescript"),
+        "line_longer_than_max": pfile("src/app/longline.py", "irrelevant", [
+            ent("dense", "\n".join([body(3), huge_line, body(2), huge_line, huge_line, body(4)]), sig="def dense():", start=7)]),
+        "no_entities_fallback": pfile("docs/notes.py", body(75, blank_every=5), []),
+        "no_entities_short": pfile("docs/short.py", "x = 1\ny = 2\n", []),
+        "blank_content": pfile("docs/blank.py", "  \n\n\t\n", []),
+        "trailing_newlines": pfile("src/app/trail.py", "irrelevant", [ent("padded", body(30) + "\n\n\n", sig="def padded():", start=5)]),
+    }
+    params = [dict(max_tokens=None, overlap_tokens=None), dict(max_tokens=60, overlap_tokens=15), dict(max_tokens=60, overlap_tokens=0),
+              dict(max_tokens=25, overlap_tokens=40), dict(max_tokens=40, overlap_tokens=5), dict(max_tokens=12, overlap_tokens=3)]
+    return files, params
+
+
+def compact_chunk(c):
+    """Long contents are frozen as sha1 + length (an equally strong pin at a fraction of the fixture size)."""
+    import hashlib
+    d = dataclasses.asdict(c)
+    if len(d["content"]) > 160:
+        text = d.pop("content")
+        d["content_sha1"], d["content_len"] = hashlib.sha1(text.encode()).hexdigest(), len(text)
+    return d
+
+
+def run_chunker(R):
+    files, params = chunker_scenarios()
+    Lang, EType = R.types.Language, R.types.EntityType
+
+    def build_entity(d):
+        return R.pmodels.CodeEntity(type=EType(d["type"]), name=d["name"], qualified_name=d["qualified_name"], signature=d["signature"],
+                                    docstring=d["docstring"], code=d["code"], start_line=d["start_line"], end_line=d["end_line"],
+                                    children=[build_entity(c) for c in d["children"]])
+
+    cases = []
+    for fname, f in files.items():
+        info = R.pmodels.FileInfo(path=Path(f["path"]), relative_path=f["path"], language=Lang(f["language"]), content_hash=f["content_hash"],
+                                  size_bytes=len(f["content"]), line_count=f["content"].count("\n") + 1)
+        parsed = R.pmodels.ParsedFile(file_info=info, content=f["content"], entities=[build_entity(e) for e in f["entities"]])
+        for p in params:
+            for project in (None, "demo"):
+                chunks = R.chunker.CodeChunker(**p).chunk_file(parsed, project_name=project)
+                cases.append({"file": fname, "params": p, "project_name": project, "chunks": [compact_chunk(c) for c in chunks]})
+                if p["max_tokens"] != 60:           # the project_name pass-through needs only one parameter set
+                    break
+    return {"generator": "tests/golden/gen_goldens.py", "reference": "src/lattice/embeddings/chunker.py:40-217",
+            "token_counter": "len(text.split()) stand-in for tiktoken cl100k_base (absent offline)",
+            "settings": {"chunk_max_tokens": 1000, "chunk_overlap_tokens": 200}, "files": files, "cases": cases}
+
 
 def main():
     R = load_reference()
@@ -366,6 +453,7 @@ def main():
     shapes = asyncio.run(run_callshapes(R))
     shapes["fallback_plans"] = plans
     (OUT / "callshapes_reference.json").write_text(json.dumps(shapes, indent=1, sort_keys=True, default=str))
+    (OUT / "chunker_reference.json").write_text(json.dumps(run_chunker(R), sort_keys=True, separators=(",", ":"), default=str))
     print("wrote", OUT / "ranking_reference.json", "and", OUT / "callshapes_reference.json")
 
 
