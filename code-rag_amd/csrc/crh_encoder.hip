@@ -94,18 +94,24 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *row = ids + (size_t)b * L;
     const int nw = (L + 63) >> 6;                    // mask words per row (L is a multiple of 16, not necessarily of 64)
+    __shared__ int wcnt[16];                       // real tokens per 64-token word (L <= 1024)
     for (int t0 = wave * 64; t0 < L; t0 += 256) {  // validity bitmask, 64 tokens per wave step
         const bool v = (t0 + lane < L) && row[t0 + lane] != pad_id;
         const unsigned long long m = __ballot(v);
-        if (lane == 0) kmask[(size_t)b * nw + (t0 >> 6)] = m;
-    }
-    if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < L; ++t) {
-            const bool v = row[t] != pad_id;
-            run += v ? 1 : 0;
-            posid[t] = (v ? run : 0) + pad_id;
+        if (lane == 0) {
+            kmask[(size_t)b * nw + (t0 >> 6)] = m;
+            wcnt[t0 >> 6] = __popcll(m);
         }
+    }
+    // position of token t = number of real tokens up to and including t: whole 64-token words before it (their popcounts
+    // meet in LDS) + the bits of its own word up to its lane.  (Thread 0 walking the row was L dependent loads: 42 us at L = 128.)
+    __syncthreads();
+    for (int t0 = wave * 64; t0 < L; t0 += 256) {
+        const bool v = (t0 + lane < L) && row[t0 + lane] != pad_id;
+        const unsigned long long m = __ballot(v);
+        int run = __popcll(m & ((2ull << lane) - 1ull));
+        for (int w = 0; w < (t0 >> 6); ++w) run += wcnt[w];
+        if (t0 + lane < L) posid[t0 + lane] = (v ? run : 0) + pad_id;
     }
     __syncthreads();
     constexpr int per = 3;  // D == 768: 3 groups of 4 elements per lane
@@ -694,25 +700,52 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
 
 // ------------------------------------------------------------------ masked mean pool
 
-// grid = (D/256, B), block 256: sent[b][d] = sum_{valid t} tok[b][t][d] / #valid    (unixcoder_provider.py:152-154)
+// grid = (D/128, B), block 256: sent[b][d] = sum_{valid t} tok[b][t][d] / #valid    (unixcoder_provider.py:152-154)
+// A lane owns two adjacent dims, wave w the tokens t = w (mod 4), eight of them in flight at a time (selected by the mask
+// bit after the load: padded rows are real memory); the four partial sums are added in wave order.  (One thread per dim
+// walking every token behind a branch on its mask bit was a chain of L dependent loads: 31 us at B = 16, L = 128.)
 __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, const unsigned long long *__restrict__ kmask,
                                               float *__restrict__ sent, int L, int D)
 {
-    const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[4][64][2];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.x * 128 + lane * 2;
     const int nw = (L + 63) >> 6;
     const unsigned long long *km = kmask + (size_t)b * nw;
-    float acc = 0.f;
-    int cnt = 0;
-    for (int t64 = 0; t64 < nw; ++t64) {
-        const unsigned long long m = km[t64];
-        cnt += __popcll(m);
-        for (int j = 0; j < 64; ++j)
-            if ((m >> j) & 1ull) acc += bf2f(tok[((size_t)b * L + t64 * 64 + j) * D + d]);
+    const bf16_t *base = tok + (size_t)b * L * D + d;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = wave; t < L; t += 32) {
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tt = t + 4 * i;
+            v[i] = tt < L ? *reinterpret_cast<const uint32_t *>(base + (size_t)tt * D) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tt = t + 4 * i;
+            const bool on = tt < L && ((km[tt >> 6] >> (tt & 63)) & 1ull);
+            a0 += on ? bf2f(v[i] & 0xffffu) : 0.f;
+            a1 += on ? bf2f(v[i] >> 16) : 0.f;
+        }
     }
-    sent[(size_t)b * D + d] = acc / (float)cnt;  // an all-pad row divides 0/0 exactly like the reference's mean
+    part[wave][lane][0] = a0;
+    part[wave][lane][1] = a1;
+    __syncthreads();
+    if (wave) return;
+    int cnt = 0;
+    for (int w = 0; w < nw; ++w) cnt += __popcll(km[w]);
+    float s0 = part[0][lane][0], s1 = part[0][lane][1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        s0 += part[w][lane][0];
+        s1 += part[w][lane][1];
+    }
+    // an all-pad row divides 0/0 exactly like the reference's mean
+    *reinterpret_cast<float2 *>(sent + (size_t)b * D + d) = float2{s0 / (float)cnt, s1 / (float)cnt};
 }
 
-// ------------------------------------------------------------------ skinny GEMM (T <= 512: the query path)
+// ------------------------------------------------------------------ skinny GEMM (a handful of rows)
 //
 // One short query is 32-64 tokens: the tiled kernels above would run one 256-row tile per column block with a handful of
 // rows in it, ~15 us per call, 48 calls per forward.  Here a workgroup owns 16 output columns and a slab of <= 64 rows; its four
@@ -728,7 +761,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    // blockIdx.y selects a slab of 64 rows (T <= 512: up to eight slabs, each re-reading W)
+    // blockIdx.y selects a slab of 64 rows (each slab re-reads W)
     const int row0 = blockIdx.y * 64;
     A += (size_t)row0 * K;
     C += (size_t)row0 * N;
@@ -796,6 +829,119 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t *__restrict__ 
     *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
 }
 
+// ------------------------------------------------------------------ mid-size GEMM (512 < T <= a few thousand rows)
+//
+// Between the query path and the big index-time batches the 256-row tiles run out of parallelism: at T = 2048 the N = 768
+// GEMMs are 48 workgroups on 256 CUs, each walking its whole K in series with every LDS-DMA exposed to the full HBM/MALL
+// latency (measured 1.1 us per k-step against 0.45 in steady state; 34 us per call, 54 % of the forward).  What is missing
+// there is bytes in flight, not MFMA rate -- so: 64 x 64 tiles (8x the workgroups), two workgroups per CU, a 4-stage ring
+// with three k-steps in flight per workgroup, and one raw barrier per step.  Staging, swizzle and the C^T fragment layout
+// are k_gemm_nt's.  (A first version fetched MFMA operands straight from global memory, like k_gemm_skinny: a wave's
+// 16-byte pieces of 16 different rows cost the texture path one cache line each, and it stalled at ~260 TFLOP/s whatever
+// the size -- LDS-DMA moves 8 full 128-byte rows per instruction.)  N % 64 == 0, K % 64 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_mid(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ C, int M, int N, int K)
+{
+    constexpr int TM = 64, TN = 64, S = 4;
+    constexpr int kStage = (TM + TN) * BK * 2;   // 16 KiB: A rows then W rows, 16 pieces of 1 KiB, 4 per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * kStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, c16 = lane & 15;
+    // workgroups are dealt round-robin over the 8 XCDs: give each XCD label a contiguous run of tiles (row panels), so the
+    // column tiles sharing an A panel meet in one L2
+    const int nb = N / TN, ntiles = ((M + TM - 1) / TM) * nb;
+    const int run = (ntiles + 7) >> 3;
+    const int t = (blockIdx.x & 7) * run + (blockIdx.x >> 3);
+    if (t >= ntiles) return;                     // (before any barrier)
+    const int m0 = (t / nb) * TM, n0 = (t % nb) * TN;
+    const int nk = K / BK;
+    const bf16_t *src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);   // row of the stacked [A;W] image: waves 0,1 stage A, waves 2,3 W
+        const int c = (lane & 7) ^ (r & 7);               // slot s of row r holds chunk s ^ (r & 7)
+        if (wave < 2) {
+            int m = m0 + r;
+            m = m < M ? m : M - 1;                        // rows past M: a valid row, result never stored
+            src[i] = A + (size_t)m * K + c * 8;
+        } else {
+            src[i] = W + (size_t)(n0 + r - TM) * K + c * 8;
+        }
+    }
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(smem + (kt & (S - 1)) * kStage + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+    for (int kt = 0; kt < 3 && kt < nk; ++kt) issue(kt);
+    f32x4 acc[2][2];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < nk; ++it) {
+        // stage `it` has landed once only the stages issued after it (at most two, 4 pieces each) remain outstanding
+        const int later = nk - 1 - it;
+        if (later >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // every wave's pieces of stage `it` are in; all reads of stage it-1 are done
+        if (it + 3 < nk) issue(it + 3);          // into the buffer stage it-1 just vacated
+        const unsigned char *sa = smem + (it & (S - 1)) * kStage;
+        const unsigned char *sw = sa + TM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fw[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                fa[b] = *reinterpret_cast<const bf16x8 *>(sa + lds_off(wm * 32 + b * 16 + c16, g + 4 * ks));
+                fw[b] = *reinterpret_cast<const bf16x8 *>(sw + lds_off(wn * 32 + b * 16 + c16, g + 4 * ks));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    // a lane holds, per (nt, mt), the 4 consecutive n = n0 + wn*32 + nt*16 + 4g + {0..3} of row m = m0 + wm*32 + mt*16 + c16
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 32 + nt * 16 + 4 * g;
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + wm * 32 + mt * 16 + c16;
+            if (m >= M) continue;
+            float o0 = acc[nt][mt][0] + b4.x, o1 = acc[nt][mt][1] + b4.y, o2 = acc[nt][mt][2] + b4.z, o3 = acc[nt][mt][3] + b4.w;
+            if (EPI == 1) {
+                const f32x2_t ga = gelu_erf2(f32x2_t{o0, o1}), gb = gelu_erf2(f32x2_t{o2, o3});
+                o0 = ga.x;
+                o1 = ga.y;
+                o2 = gb.x;
+                o3 = gb.y;
+            }
+            if (EPI == 2) {
+                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
+                o0 += bf2f(r2.x & 0xffffu);
+                o1 += bf2f(r2.x >> 16);
+                o2 += bf2f(r2.y & 0xffffu);
+                o3 += bf2f(r2.y >> 16);
+            }
+            u32x2 o;
+            o.x = pack2(o0, o1);
+            o.y = pack2(o2, o3);
+            *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
+        }
+    }
+}
+
 #include "crh_gemm256.hpp"
 
 }  // namespace enc
@@ -808,6 +954,15 @@ namespace {
 // Grid: a multiple of 8 workgroups (one XCD label each).  Default: persistent, capped at the CU count, each workgroup walking
 // several tiles with one pipeline (whole forward 9.06 vs 9.29 ms against one workgroup per tile, same process, B=256 L=128;
 // the two are within a few percent -- CODERAG_HIP_GEMM_PERSISTENT=0 selects one workgroup per tile).
+// Both tiled kernels hand each of the 8 XCD labels a contiguous share of the row panels (>= 16 panels) or of the tiles, and a
+// label's gridDim/8 workgroups stride through that share: size the grid by the BUSIEST label.  (Sizing it by the total --
+// min(tiles, CUs) -- gave T = 5120, N = 768 a grid of 120: 15 workgroups per label for the 18 tiles of a 3-panel label,
+// i.e. two rounds, 93 us against 50 at both T = 4096 and T = 6144.)
+unsigned xcd_grid(int64_t panels, int64_t nb, int64_t max_per_label)
+{
+    const int64_t busiest = panels >= 16 ? crh::ceil_div(panels, 8) * nb : crh::ceil_div(panels * nb, 8);
+    return (unsigned)(8 * std::max<int64_t>(1, std::min(busiest, max_per_label)));
+}
 unsigned gemm_grid(int T, int N)
 {
     static int cus = 0, persistent = -1;
@@ -819,23 +974,11 @@ unsigned gemm_grid(int T, int N)
         const char *e = getenv("CODERAG_HIP_GEMM_PERSISTENT");
         persistent = (e && e[0] == '0') ? 0 : 1;
     }
-    const int64_t tiles = crh::ceil_div(T, BM) * (N / BN);
-    const int64_t want = persistent ? std::min<int64_t>(tiles, (cus / 8) * 8) : tiles;
-    return (unsigned)(crh::ceil_div(want, 8) * 8);
+    return xcd_grid(crh::ceil_div(T, BM), N / BN, persistent ? cus / 8 : INT32_MAX);
 }
 
-// The 256x256 ping-pong kernel (crh_gemm256.hpp) takes over when its shape constraints hold and there are enough tiles
-// to give every CU at least one; CODERAG_HIP_GEMM256=0 keeps everything on k_gemm_nt, =2 forces it whenever the shape allows.
-int gemm256_mode()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("CODERAG_HIP_GEMM256");
-        mode = e ? atoi(e) : 1;
-    }
-    return mode;
-}
-// T <= 512 rows (one query, a few short ones): k_gemm_skinny; CODERAG_HIP_SKINNY=0 keeps the tiled kernel
+// T <= 16 rows (one very short query): k_gemm_skinny; from 17 rows on k_gemm_mid is faster (tools/enc_mid_bench.py: one
+// text of 64 tokens 0.53 vs 0.70 ms, 256 tokens 0.68 vs 1.03).  CODERAG_HIP_SKINNY=0 turns it off, CODERAG_HIP_SKINNY_MAX_T moves the edge
 bool use_skinny(int T, int N, int K)
 {
     static int on = -1;
@@ -846,16 +989,54 @@ bool use_skinny(int T, int N, int K)
     static int tmax = 0;
     if (!tmax) {
         const char *e = getenv("CODERAG_HIP_SKINNY_MAX_T");
-        tmax = e ? atoi(e) : 512;   // measured crossover against the tiled kernel (tools/latency_bench.py)
+        tmax = e ? atoi(e) : 16;
     }
     return on && T <= tmax && N % 16 == 0 && K % 128 == 0;
 }
-bool use_gemm256(int T, int N, int K)
+template <int EPI>
+int launch_mid(const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
 {
-    if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || gemm256_mode() == 0) return false;
-    if ((int64_t)T * K * 2 >= (1LL << 32) || (int64_t)N * K * 2 >= (1LL << 32)) return false;   // its cursor uses 32-bit byte offsets
-    const int64_t tiles = crh::ceil_div(T, g256::BM) * (N / g256::BN);
-    return gemm256_mode() == 2 || tiles >= 256;
+    const int64_t tiles = crh::ceil_div(T, 64) * (N / 64);
+    hipLaunchKernelGGL((k_gemm_mid<EPI>), dim3((unsigned)(crh::ceil_div(tiles, 8) * 8)), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+                       (const bf16_t *)res, (bf16_t *)y, T, N, K);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+// ---- which tiled kernel?  Above the skinny range three kernels compete and the winner flips with the shape (measured per
+// GEMM, tools/gemm_mid_sweep.py): a launch costs (rounds of its busiest XCD label) x (one tile's walk through K), so
+// k_gemm_nt wins while its 256x128 tiles fill the chip in one round, the 256x256 ping-pong kernel wherever halving the
+// tile count saves a round (and everywhere at scale), k_gemm_mid while both leave most CUs idle.  The constants are fits
+// (us) to that sweep at K = 768 / 3072; later rounds of a persistent launch overlap with the previous one (x 0.85).
+enum GemmKernel { GEMM_NT, GEMM_PP, GEMM_MID };
+int env_mode(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+bool pp_allowed(int T, int N, int K)
+{
+    if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK) return false;
+    return (int64_t)T * K * 2 < (1LL << 32) && (int64_t)N * K * 2 < (1LL << 32) && (int64_t)T * N * 2 < (1LL << 32);   // 32-bit byte offsets
+}
+GemmKernel choose_gemm(int T, int N, int K, int act)
+{
+    static const int pp_mode = env_mode("CODERAG_HIP_GEMM256", 1);   // 0 never, 1 by cost, 2 whenever the shape allows
+    static const int mid_mode = env_mode("CODERAG_HIP_MID", 1);      // 0 never, 1 by cost, 2 whenever the shape allows
+    const bool pp_ok = pp_mode != 0 && pp_allowed(T, N, K), mid_ok = mid_mode != 0 && N % 64 == 0;
+    if (mid_ok && mid_mode == 2) return GEMM_MID;
+    if (pp_ok && pp_mode == 2) return GEMM_PP;
+    const double kf = K / 768.0;
+    auto tiled = [&](int bm, int bn, double per_round) {
+        const int64_t panels = crh::ceil_div(T, bm), nb = N / bn;
+        const int64_t busiest = panels >= 16 ? crh::ceil_div(panels, 8) * nb : crh::ceil_div(panels * nb, 8);
+        const int64_t rounds = crh::ceil_div(busiest, 32);
+        return per_round * (1.0 + 0.85 * (double)(rounds - 1));
+    };
+    const double nt = tiled(BM, BN, 11.0 * kf + 6.0 + (act ? 2.0 : 0.0));
+    const double pp = pp_ok ? tiled(g256::BM, g256::BN, 13.0 * kf + 8.5 + (act ? 3.5 : 0.0)) : 1e30;
+    const double mid = mid_ok ? 4.5 + 1.9 * kf + (double)(crh::ceil_div(T, 64) * (N / 64)) * kf * 0.0103 * (act ? 1.25 : 1.0) : 1e30;
+    if (mid < nt && mid < pp) return GEMM_MID;
+    return pp < nt ? GEMM_PP : GEMM_NT;
 }
 unsigned gemm256_grid(int T, int N)
 {
@@ -867,9 +1048,7 @@ unsigned gemm256_grid(int T, int N)
             cus = prop.multiProcessorCount;
         cached = cus;
     }
-    const int64_t tiles = crh::ceil_div(T, g256::BM) * (N / g256::BN);
-    const int64_t want = std::min<int64_t>(tiles, (cached / 8) * 8);
-    return (unsigned)(crh::ceil_div(want, 8) * 8);
+    return xcd_grid(crh::ceil_div(T, g256::BM), N / g256::BN, cached / 8);
 }
 int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
 {
@@ -924,7 +1103,9 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     }
-    if (use_gemm256(T, N, K)) return launch_gemm256(act, x, w, bias, nullptr, y, T, N, K, st);
+    const GemmKernel which = choose_gemm(T, N, K, act);
+    if (which == GEMM_MID) return act == 1 ? launch_mid<1>(x, w, bias, nullptr, y, T, N, K, st) : launch_mid<0>(x, w, bias, nullptr, y, T, N, K, st);
+    if (which == GEMM_PP) return launch_gemm256(act, x, w, bias, nullptr, y, T, N, K, st);
     const dim3 grid(gemm_grid(T, N));
     CRH_TRY(gemm_lds_attr());
     if (act == 1)
@@ -1006,7 +1187,14 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     }
-    if (use_gemm256(T, N, K) && K <= 1024 && y != residual) {
+    const GemmKernel which = choose_gemm(T, N, K, 0);
+    if (which == GEMM_MID) {     // (in place is fine: a lane reads exactly the residual elements it then overwrites)
+        CRH_TRY(launch_mid<2>(x, w, bias, residual, y, T, N, K, st));
+        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
+    if (which == GEMM_PP && K <= 1024 && y != residual) {
         // short K: the residual joins in the LayerNorm kernel instead of the GEMM epilogue (see k_layernorm768_res)
         CRH_TRY(launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st));
         hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma,
@@ -1014,7 +1202,7 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     }
-    if (use_gemm256(T, N, K)) {
+    if (which == GEMM_PP) {
         CRH_TRY(launch_gemm256(2, x, w, bias, residual, y, T, N, K, st));
         hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
         CRH_HIP(hipGetLastError());
@@ -1083,8 +1271,8 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
 int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D, void *stream)
 {
     if (!tok || !kmask || !sent) return fail(CRH_E_INVALID, "pool: NULL pointer");
-    if (B <= 0 || L <= 0 || L % 16 || D % 256) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
-    hipLaunchKernelGGL(k_pool, dim3(D / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
+    if (B <= 0 || L <= 0 || L % 16 || D % 128) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
+    hipLaunchKernelGGL(k_pool, dim3(D / 128, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
                        (const unsigned long long *)kmask, sent, L, D);
     CRH_HIP(hipGetLastError());
     return CRH_OK;

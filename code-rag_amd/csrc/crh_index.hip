@@ -113,7 +113,8 @@ int ensure_stage_in(crh_index *h, int64_t bytes)
     if (h->stage_in_bytes >= bytes) return CRH_OK;
     if (h->stage_in) (void)hipFree(h->stage_in);
     h->stage_in = nullptr;
-    h->stage_in_bytes = 0;
+    h->stage_in_bytes = 0;   // (sizes are cleared before every reallocation below too: a failed hipMalloc must not leave a
+                             // recorded size next to a NULL pointer for the next call to trust)
     CRH_HIP(hipMalloc(&h->stage_in, (size_t)bytes));
     h->stage_in_bytes = bytes;
     return CRH_OK;
@@ -131,20 +132,22 @@ int scan_blocks(const crh_index *h, int64_t nitems)
 int ensure_workspace(crh_index *h, int wave_cap, int qcap)
 {
     const int blocks = h->cu_count;
-    if (!h->qn) {
-        CRH_TRY(dev_alloc(&h->qn, (int64_t)kMaxQ * h->dim));
-        CRH_TRY(dev_alloc(&h->qfrag, (int64_t)2 * h->ksteps * 64));
-        CRH_TRY(dev_alloc(&h->tau, kMaxQ));
+    if (!h->qn) CRH_TRY(dev_alloc(&h->qn, (int64_t)kMaxQ * h->dim));
+    if (!h->qfrag) CRH_TRY(dev_alloc(&h->qfrag, (int64_t)2 * h->ksteps * 64));
+    if (!h->tau) CRH_TRY(dev_alloc(&h->tau, kMaxQ));
+    if (!h->status) {
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
         CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
     }
     if (h->ws_seed < h->seed_tiles) {
         dev_free(h->gmax);
+        h->ws_seed = 0;
         CRH_TRY(dev_alloc(&h->gmax, (int64_t)h->seed_tiles * kMaxQ));
         h->ws_seed = h->seed_tiles;
     }
     if (h->ws_mask_tiles < h->cap_tiles) {
         dev_free(h->effmask);
+        h->ws_mask_tiles = 0;
         CRH_TRY(dev_alloc(&h->effmask, h->cap_tiles));
         h->ws_mask_tiles = h->cap_tiles;
     }
@@ -152,6 +155,7 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
         const int64_t bytes = (int64_t)blocks * kWaves * wave_cap * 16;
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "candidate workspace of %lld bytes exceeds the budget", (long long)bytes);
         dev_free(h->wave_lists);
+        h->ws_blocks = h->ws_wave_cap = 0;
         CRH_TRY(dev_alloc(&h->wave_lists, (int64_t)blocks * kWaves * wave_cap));
         h->ws_blocks = blocks;
         h->ws_wave_cap = wave_cap;
@@ -161,6 +165,7 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "per-query candidate lists of %lld bytes exceed the budget", (long long)bytes);
         dev_free(h->qlist);
         dev_free(h->skeys);
+        h->ws_qcap = 0;
         CRH_TRY(dev_alloc(&h->qlist, (int64_t)kMaxQ * qcap));
         CRH_TRY(dev_alloc(&h->skeys, (int64_t)kMaxQ * qcap));
         h->ws_qcap = qcap;
@@ -641,6 +646,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         const int64_t elems = (int64_t)nq * h->dim;
         if (h->stage_q_elems < elems) {
             dev_free(h->stage_q);
+            h->stage_q_elems = 0;
             CRH_TRY(dev_alloc(&h->stage_q, elems));
             h->stage_q_elems = elems;
         }
@@ -654,6 +660,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         if (h->stage_out_elems < elems) {
             dev_free(h->stage_os);
             dev_free(h->stage_or);
+            h->stage_out_elems = 0;
             CRH_TRY(dev_alloc(&h->stage_os, elems));
             CRH_TRY(dev_alloc(&h->stage_or, elems));
             h->stage_out_elems = elems;
@@ -739,7 +746,12 @@ int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int
     if (total > 8192) return fail(CRH_E_CAPACITY, "nlists*k=%d exceeds 8192", total);
     int P = 1;
     while (P < total) P <<= 1;
-    const size_t lds = (size_t)P * 4 + 8 + (size_t)P * 8;
+    const size_t lds = (size_t)P * 4 + 8 + (size_t)P * 8;   // 96 KiB at P = 8192: above the 64 KiB a launch gets by default
+    static bool attr = false;
+    if (!attr) {
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12 + 8));
+        attr = true;
+    }
     hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), lds, static_cast<hipStream_t>(stream), nlists, nq, k, scores_dev, rows_dev,
                        out_scores_dev, out_rows_dev);
     CRH_HIP(hipGetLastError());

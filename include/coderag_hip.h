@@ -243,7 +243,9 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
 int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream);
 
 /* out[b, t, :] = LN((word[ids[b,t]] + type[0]) + pos[pos_id]); pos_id = cumsum(ids != pad) * (ids != pad) + pad.
- * ids int32 [B, L]; tables bf16; out bf16 [B, L, 768].  Also writes kmask (see above). */
+ * ids int32 [B, L]; tables bf16; out bf16 [B, L, 768].  Also writes kmask (see above).
+ * The library is not told the table heights: every id must index a row of `word`, and `pos` must hold
+ * pad_id + L + 1 rows -- the caller checks (the Python driver does, encoder.py `_check_ids`). */
 int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const void *type0,
                  const float *gamma, const float *beta, float eps, int pad_id, void *out,
                  uint64_t *kmask, int B, int L, int D, void *stream);

@@ -24,8 +24,8 @@ def _close(torch, got, ref, rel, abs_):
 
 
 # T >= 3841 rows exercises the per-XCD super-tile order (>= 16 panels), smaller T the linear order; ragged T the row guards
-# T <= 512 goes to the skinny kernel (k_gemm_skinny: the query path)
-@pytest.mark.parametrize("T,N,K,act", [(1, 768, 768, 0), (17, 2304, 768, 0), (64, 3072, 768, 1), (33, 768, 3072, 0), (48, 768, 256, 1), (65, 2304, 768, 0), (200, 3072, 768, 1), (256, 768, 3072, 0), (500, 2304, 768, 0), (513, 768, 768, 0),
+# T <= 16 goes to k_gemm_skinny, everything else below a few thousand rows to k_gemm_mid (the cost model in crh_encoder.hip)
+@pytest.mark.parametrize("T,N,K,act", [(1, 768, 768, 0), (16, 2304, 768, 0), (9, 3072, 768, 1), (16, 768, 3072, 0), (2, 768, 256, 1), (17, 2304, 768, 0), (64, 3072, 768, 1), (33, 768, 3072, 0), (48, 768, 256, 1), (65, 2304, 768, 0), (200, 3072, 768, 1), (256, 768, 3072, 0), (500, 2304, 768, 0), (513, 768, 768, 0),
                                        (384, 768, 768, 0), (200, 2304, 768, 0), (130, 3072, 768, 1), (256, 768, 3072, 0), (500, 2304, 768, 0), (513, 768, 768, 0),
                                        (5000, 2304, 768, 0), (9300, 3072, 768, 1), (4097, 768, 3072, 0)])
 def test_gemm_bias_act(gpu, T, N, K, act):
@@ -41,6 +41,25 @@ def test_gemm_bias_act(gpu, T, N, K, act):
         ref = torch.nn.functional.gelu(ref)             # erf form
     torch.cuda.synchronize()
     _close(torch, y, ref, rel=2 ** -7, abs_=2e-3)           # one bf16 rounding of the result + f32 accumulation order
+
+
+# k_gemm_mid (64x64 tiles, 4-stage LDS-DMA ring): full and ragged last row tiles, every epilogue
+@pytest.mark.parametrize("T,N,K,act", [(600, 768, 768, 0), (1000, 2304, 768, 0), (2048, 3072, 768, 1), (1537, 768, 3072, 0), (4096, 768, 3072, 0),
+                                       (4095, 2304, 768, 1), (577, 128, 256, 1), (2049, 3072, 768, 0)])
+def test_gemm_mid_shapes(gpu, T, N, K, act):
+    torch, ffi, dev = _env()
+    g = torch.Generator(device="cpu").manual_seed(T + N)
+    a = torch.randn((T, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((N,), generator=g).to(dev)
+    y = torch.full((T + 8, N), 7.0, dtype=torch.bfloat16, device=dev)     # 8 guard rows: nothing may be written past T
+    ffi.check(ffi.lib().crh_gemm_bf16_bias(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, act, 0))
+    ref = a.float() @ w.float().T + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    torch.cuda.synchronize()
+    _close(torch, y[:T], ref, rel=2 ** -7, abs_=2e-3)
+    assert bool((y[T:] == 7.0).all())
 
 
 # The 256x256 ping-pong kernel (crh_gemm256.hpp) takes over from 256 tiles up: large T through the public entry, and
@@ -86,7 +105,8 @@ def test_gemm256_repeatable(gpu):
         assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
 
 
-@pytest.mark.parametrize("T,K", [(1, 768), (40, 3072), (64, 768), (129, 3072), (256, 768), (257, 768), (300, 3072), (6000, 768), (22100, 3072), (23040, 768)])
+@pytest.mark.parametrize("T,K", [(1, 768), (40, 3072), (64, 768), (129, 3072), (256, 768), (257, 768), (300, 3072), (6000, 768), (22100, 3072), (23040, 768),
+                                 (513, 768), (1000, 3072), (2048, 3072), (4095, 768), (4096, 3072), (16, 3072), (17, 768)])
 def test_gemm_residual_layernorm(gpu, T, K):
     torch, ffi, dev = _env()
     g = torch.Generator(device="cpu").manual_seed(K)
@@ -221,8 +241,8 @@ def test_provider_end_to_end(gpu):
         return one, many
     one, many = asyncio.run(go())
     assert p.embedding_dim == 768 and len(one) == 768 and isinstance(one[0], float) and len(many) == 4
-    # same text in different batches: the GEMM kernel is chosen by the batch's token count (<= 64 rows: the split-K skinny
-    # kernel) and the kernels differ in f32 summation order, so equality holds to bf16 accuracy, not to the bit
+    # same text in different batches: the GEMM kernel is chosen by the batch's token count and the kernels differ in f32
+    # summation order, so equality holds to bf16 accuracy, not to the bit
     assert np.abs(np.asarray(many[0]) - np.asarray(many[3])).max() <= 2e-2 * np.abs(np.asarray(one)).max()
     assert np.abs(np.asarray(one) - np.asarray(many[0])).max() <= 2e-2 * np.abs(np.asarray(one)).max()
     assert not np.allclose(many[0], many[1], atol=1e-3)

@@ -374,3 +374,31 @@ def test_randomised_configurations_against_the_oracle(gpu):
         except AssertionError as e:
             raise AssertionError(f"case {case}: dim={dim} bf16={bf16} n={n} nq={nq} k={k} ncols={ncols} filt={filt} base={base}: {e}")
         idx.close()
+
+
+@pytest.mark.parametrize("nlists,k", [(8, 1000), (2, 4096), (8, 1024), (3, 7), (1, 1)])
+def test_merge_topk_large_lists(gpu, nlists, k):
+    """The all-gather merge at its largest shapes (nlists * k up to 8192 pairs per query -- 96 KiB of LDS, above the
+    default dynamic limit) with score ties across lists and ragged padding, against the oracle's merge."""
+    import torch
+    ffi = _ffi()
+    rng = np.random.default_rng(1000 * nlists + k)
+    nq = 5
+    s = np.sort(rng.integers(0, 40, (nlists, nq, k)).astype(np.float32) / 64, axis=2)[:, :, ::-1].copy()   # heavy ties
+    r = rng.permutation(nlists * nq * k).astype(np.int64).reshape(nlists, nq, k)
+    for l in range(nlists):                                   # inside a list: equal scores by ascending row, as a shard returns them
+        for q in range(nq):
+            order = np.lexsort((r[l, q], -s[l, q]))
+            s[l, q], r[l, q] = s[l, q][order], r[l, q][order]
+    cut = max(1, k // 3)
+    s[-1, :, cut:], r[-1, :, cut:] = -np.inf, -1              # a short last shard
+    dev = torch.device("cuda:0")
+    ms = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    mr = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ffi.merge_topk(torch.from_numpy(s).to(dev), torch.from_numpy(r).to(dev), ms, mr, 0)
+    torch.cuda.synchronize()
+    es, er = orc.merge_topk(s, r)
+    assert np.array_equal(mr.cpu().numpy(), er) and np.array_equal(ms.cpu().numpy(), es)
+    with pytest.raises(ffi.NativeError):
+        ffi.merge_topk(torch.zeros((9, 1, 1000), dtype=torch.float32, device=dev), torch.zeros((9, 1, 1000), dtype=torch.int64, device=dev),
+                       torch.empty((1, 1000), dtype=torch.float32, device=dev), torch.empty((1, 1000), dtype=torch.int64, device=dev), 0)
