@@ -55,4 +55,19 @@ struct DeviceGuard {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) applies to the CURRENT device only: one flag per device, not per process.
+// need() is true the first time it is asked on a device.  (A race between two threads repeats an idempotent call.)
+struct OncePerDevice {
+    bool done[64] = {};
+    bool need()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return true;
+        d &= 63;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 }  // namespace crh

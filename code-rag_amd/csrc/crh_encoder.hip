@@ -1052,12 +1052,11 @@ unsigned gemm256_grid(int T, int N)
 }
 int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
 {
-    static bool attr = false;
-    if (!attr) {
+    static OncePerDevice once;
+    if (once.need()) {
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
-        attr = true;
     }
     const dim3 grid(gemm256_grid(T, N)), block(g256::WAVES * 64);
     const bf16_t *xa = (const bf16_t *)x, *wa = (const bf16_t *)w, *ra = (const bf16_t *)res;
@@ -1076,12 +1075,11 @@ constexpr size_t kGemmLds = (size_t)STAGES * (BM + BN) * BK * 2;  // 144 KB of t
 
 int gemm_lds_attr()
 {
-    static bool done = false;
-    if (!done) {
+    static OncePerDevice once;
+    if (once.need()) {
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
-        done = true;
     }
     return CRH_OK;
 }
@@ -1232,10 +1230,9 @@ int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B
     const int nqt = L / 16;
 #define CRH_ATTN(NW_, QT_)                                                                                                      \
     do {                                                                                                                        \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set) {                                                                                                        \
+        static OncePerDevice once;                                                                                              \
+        if (once.need()) {                                                                                                      \
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<NW_, QT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256)); \
-            attr_set = true;                                                                                                    \
         }                                                                                                                       \
         hipLaunchKernelGGL((k_attn<NW_, QT_>), dim3(H, B), dim3(NW_ * 64), lds, st, (const bf16_t *)qkv,                        \
                            (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);                                 \

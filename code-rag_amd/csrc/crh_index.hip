@@ -747,11 +747,8 @@ int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int
     int P = 1;
     while (P < total) P <<= 1;
     const size_t lds = (size_t)P * 4 + 8 + (size_t)P * 8;   // 96 KiB at P = 8192: above the 64 KiB a launch gets by default
-    static bool attr = false;
-    if (!attr) {
-        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12 + 8));
-        attr = true;
-    }
+    static OncePerDevice once;
+    if (once.need()) CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12 + 8));
     hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), lds, static_cast<hipStream_t>(stream), nlists, nq, k, scores_dev, rows_dev,
                        out_scores_dev, out_rows_dev);
     CRH_HIP(hipGetLastError());
