@@ -82,7 +82,9 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // ------------------------------------------------------------------ embeddings + LayerNorm
 
-// grid = B, block = 256.  ids int32 [B,L]; out bf16 [B,L,768]; kmask u64 [B][L/64] (bit = ids != pad).
+// grid = (B, L/16), block = 256: a workgroup embeds 16 tokens of one row (one row per workgroup left a single query on one
+// CU walking its tokens in series: 20 us for 64 tokens); every workgroup of a row redoes the row's cheap mask / position scan,
+// the first one writes the mask words.  ids int32 [B,L]; out bf16 [B,L,768]; kmask u64 [B][L/64] (bit = ids != pad).
 // position id = cumsum(ids != pad) * (ids != pad) + pad   (modeling_roberta.py create_position_ids_from_input_ids)
 __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ ids, const bf16_t *__restrict__ word,
                                                   const bf16_t *__restrict__ pos, const bf16_t *__restrict__ type0,
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
         const bool v = (t0 + lane < L) && row[t0 + lane] != pad_id;
         const unsigned long long m = __ballot(v);
         if (lane == 0) {
-            kmask[(size_t)b * nw + (t0 >> 6)] = m;
+            if (blockIdx.y == 0) kmask[(size_t)b * nw + (t0 >> 6)] = m;
             wcnt[t0 >> 6] = __popcll(m);
         }
     }
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
     }
     __syncthreads();
     constexpr int per = 3;  // D == 768: 3 groups of 4 elements per lane
-    for (int t = wave; t < L; t += 4) {
+    for (int t = blockIdx.y * 16 + wave; t < blockIdx.y * 16 + 16; t += 4) {   // L % 16 == 0
         const bf16_t *w = word + (size_t)row[t] * D;
         const bf16_t *p = pos + (size_t)posid[t] * D;
         float x[12];
@@ -1259,7 +1261,7 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
 {
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln: NULL pointer");
     if (B <= 0 || L <= 0 || L % 16 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%16==0, D==768)", B, L, D);
-    hipLaunchKernelGGL(k_embed_ln, dim3(B), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
+    hipLaunchKernelGGL(k_embed_ln, dim3(B, L / 16), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
                        (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
