@@ -282,3 +282,50 @@ def test_checkpoint_directory_with_native_tokenizer(gpu, tmp_path):
     ids = [[hf.cls_token_id, eid, hf.sep_token_id] + hf.convert_tokens_to_ids(hf.tokenize(t))[:508] + [hf.sep_token_id] for t in texts]
     want = model.embed_ids(ids).cpu().numpy()
     assert got.shape == (len(texts), 768) and np.array_equal(got, want)
+
+
+def test_encoder_properties_on_the_bench_mix(gpu):
+    """Size-independent properties on the bench's workload shape (BASELINE configs[1]: lognormal chunk lengths, 12 layers), where
+    the oracle would take minutes: (1) the same call twice is bit-identical; (2) a chunk's embedding does not depend on what
+    else is in the call -- other neighbours, another padded length, another GEMM kernel (the batch's token count picks it) --
+    beyond bf16 accumulation-order noise; (3) trailing pad tokens change nothing beyond the same noise; (4) rows come back
+    in input order whatever the length-bucketing did."""
+    torch, ffi, dev = _env()
+    from coderag_amd import encoder as drv
+    cfg = drv.EncoderConfig()
+    model = drv.HipUniXcoder(drv.synthetic_weights(cfg, 23), cfg, drv.HashTokenizer(cfg.vocab_size), 0)
+    rng = np.random.default_rng(1234)
+    n = 3000
+    lens = np.clip(np.round(np.exp(rng.normal(np.log(160), 0.8, n))), 8, 512).astype(int)
+    ids = [[0, 6, 2] + rng.integers(3, cfg.vocab_size, int(L) - 4).tolist() + [2] for L in lens]
+    ids = [[t if t != cfg.pad_token_id else 7 for t in row] for row in ids]
+    full = model.embed_ids(ids).cpu().numpy()
+    again = model.embed_ids(ids).cpu().numpy()
+    assert np.array_equal(full, again)                                           # (1)
+    assert np.isfinite(full).all() and full.shape == (n, 768)
+    scale = np.abs(full).max(axis=1, keepdims=True)
+
+    pick = rng.choice(n, 40, replace=False)
+    alone = model.embed_ids([ids[i] for i in pick]).cpu().numpy()               # a small call: other kernels, other padding
+    assert np.abs(alone - full[pick]).max() <= 3e-2 * scale[pick].max()         # (2)
+    cos = (alone * full[pick]).sum(1) / (np.linalg.norm(alone, axis=1) * np.linalg.norm(full[pick], axis=1))
+    assert cos.min() >= 0.9995
+    print(f"batch-composition: max abs diff / max |e| = {np.abs(alone - full[pick]).max() / scale[pick].max():.2e}, min cosine {cos.min():.6f}")
+    one = model.embed_ids([ids[int(pick[0])]]).cpu().numpy()[0]                  # a call of its own (the query path)
+    assert np.abs(one - full[pick[0]]).max() <= 3e-2 * scale[pick[0]].max()
+
+    short = [ids[i] for i in pick if len(ids[i]) <= 200][:8]                     # (3) explicit padding to a longer bucket
+    t = np.full((len(short), 256), cfg.pad_token_id, dtype=np.int32)
+    for r, row in enumerate(short):
+        t[r, :len(row)] = row
+    padded = model.forward_ids(torch.from_numpy(t).to(dev)).cpu().numpy()
+    tight = model.embed_ids(short).cpu().numpy()
+    assert np.abs(padded - tight).max() <= 3e-2 * np.abs(tight).max()
+    print(f"padding: {np.abs(padded - tight).max() / np.abs(tight).max():.2e}; own call: {np.abs(one - full[pick[0]]).max() / scale[pick[0]].max():.2e}")
+
+    perm = rng.permutation(200)                                                  # (4)
+    sub = [ids[i] for i in perm]
+    got = model.embed_ids(sub).cpu().numpy()
+    assert np.abs(got - full[perm]).max() <= 3e-2 * scale[perm].max()
+    rev = model.embed_ids(sub[::-1]).cpu().numpy()
+    assert np.array_equal(rev[::-1], got)                                        # same batches, other input order: bit-identical
