@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Encoder forward at mid-size batches (1k..32k tokens) -- the regime between the skinny kernel (T <= 512) and the
-256x256 ping-pong kernel (>= 256 tiles).  Run once per dispatch setting, e.g.
+"""Encoder forward over a grid of batch shapes, from one query to 64k tokens -- the data behind the GEMM kernel choice
+(k_gemm_mid / k_gemm_nt / ping-pong, crh_encoder.hip choose_gemm).  Run once per dispatch setting, e.g.
   CODERAG_HIP_GEMM256=2 python tools/enc_mid_bench.py        (ping-pong kernel whatever the tile count)
   CODERAG_HIP_MID=0 python tools/enc_mid_bench.py           (no k_gemm_mid)
 Shapes as arguments (BxL, e.g. 16x128) replace the default sweep.  Prints device ms per forward (median of 30, torch events) and chunks/s."""
