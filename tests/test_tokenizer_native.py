@@ -102,3 +102,23 @@ def test_guards_against_foreign_vocabularies(tmp_path):
         HipUniXcoder._check_ids(fake, np.asarray([[5, 100, 7]], np.int32), np.asarray([3]))
     with pytest.raises(ValueError, match="embedding table"):
         HipUniXcoder._check_ids(fake, np.asarray([[-1, 3, 7]], np.int32), np.asarray([3]))
+
+
+def test_same_ids_on_random_code_points(toks):
+    """Strings of code points drawn from the whole Unicode range (every general category, astral planes, unassigned points;
+    surrogates excluded -- they are not text), mixed with ASCII letters / digits / spaces so that the pre-tokenizer's
+    letter / number / other / whitespace classes meet at every kind of boundary."""
+    hf, nat, _ = toks
+    rng = random.Random(11)
+    ascii_mix = list("ab Z09 _.\n\t'")
+
+    def point():
+        while True:
+            r = rng.random()
+            c = rng.randrange(0x80, 0x3000) if r < 0.5 else rng.randrange(0x3000, 0x10000) if r < 0.8 else rng.randrange(0x10000, 0x110000)
+            if not 0xD800 <= c <= 0xDFFF:
+                return chr(c)
+    texts = ["".join(point() if rng.random() < 0.6 else rng.choice(ascii_mix) for _ in range(rng.randrange(1, 24))) for _ in range(4000)]
+    ids, lens = nat.encode_bodies(texts, max_body=512)
+    bad = [t for i, t in enumerate(texts) if ids[i, :lens[i]].tolist() != _hf_ids(hf, t)]
+    assert not bad, [(repr(t), [hex(ord(ch)) for ch in t]) for t in bad[:3]]
