@@ -444,6 +444,17 @@ def main():
     ranking = {"generator": "tests/golden/gen_goldens.py", "reference": "src/lattice/query/ranking/{models,scorer,ranker,utils}.py",
                "scenarios": [dict(s, expected=run_ranking(R, s)) for s in scen]}
     (OUT / "ranking_reference.json").write_text(json.dumps(ranking, indent=1, sort_keys=True, default=str))
+    # seeded random scenarios (inputs regenerated by tests/ranking_cases.py; only digests + a readable head are stored)
+    import hashlib
+    sys.path.insert(0, str(OUT.parent))
+    import ranking_cases
+    rnd = []
+    for sc in ranking_cases.scenarios():
+        exp = json.loads(json.dumps(run_ranking(R, sc), default=str))
+        rnd.append({"name": sc["name"], "n": len(exp["ranked"]), "digest": hashlib.sha1(json.dumps(exp, sort_keys=True).encode()).hexdigest(),
+                    "head": [[r["entity_name"], r["file_path"], r["start_line"], r["source"], r["final_score"]] for r in exp["ranked"][:4]]})
+    (OUT / "ranking_random_reference.json").write_text(json.dumps({"generator": "tests/golden/gen_goldens.py + tests/ranking_cases.py", "seed": ranking_cases.SEED,
+                                                                   "cases": rnd}, indent=0, sort_keys=True))
     plans = {}
     planner = R.planner.QueryPlanner.__new__(R.planner.QueryPlanner)
     for qtext in ("how does verify_password work in UserRepository", "what calls process_payment", "where is the ConfigLoader",

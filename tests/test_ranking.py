@@ -48,3 +48,30 @@ def test_caps_and_config_override():
     w = RankingConfig().weights_for(QueryIntent.FIND_IMPLEMENTATIONS)   # intent without a row keeps defaults
     assert (w["graph_weight"], w["vector_weight"]) == (0.5, 0.5)
     assert RankingConfig().weights_for("find_call_chain")["graph_weight"] == 0.9   # plain strings work too
+
+
+# ---- 160 seeded random scenarios (tests/ranking_cases.py makes the inputs; the reference's ranker made the expected digests)
+import hashlib
+
+from tests import ranking_cases
+
+RANDOM_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_random_reference.json")))
+
+
+def test_random_scenarios_cover_the_branches():
+    cases = RANDOM_GOLD["cases"]
+    assert len(cases) == ranking_cases.N_SCENARIOS and RANDOM_GOLD["seed"] == ranking_cases.SEED
+    sources = {row[3] for c in cases for row in c["head"]}
+    assert sources == {"graph", "vector", "hybrid"}
+    assert min(c["n"] for c in cases) <= 2 and max(c["n"] for c in cases) == 35      # 7 files x the per-file cap of 5
+
+
+@pytest.mark.parametrize("case", RANDOM_GOLD["cases"], ids=lambda c: c["name"])
+def test_ranker_matches_reference_on_random_scenarios(case):
+    sc = ranking_cases.scenario(int(case["name"].split("_")[1]))
+    plan, ctx, vec, cent = build_inputs(sc)
+    ranked = HybridRanker().rank_results(plan, ctx, vec, cent)
+    got = json.loads(json.dumps({"ranked": [dataclasses.asdict(r) for r in ranked], "flattened": ranked_results_to_search_results(ranked)}, default=str))
+    head = [[r["entity_name"], r["file_path"], r["start_line"], r["source"], r["final_score"]] for r in got["ranked"][:4]]
+    assert (len(got["ranked"]), head) == (case["n"], case["head"])
+    assert hashlib.sha1(json.dumps(got, sort_keys=True).encode()).hexdigest() == case["digest"]     # every field of every result
