@@ -105,6 +105,33 @@ def test_gemm256_repeatable(gpu):
         assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
 
 
+@pytest.mark.parametrize("T,N,K,act", [(3000, 768, 3072, 0), (2049, 3072, 768, 1), (64, 768, 3072, 0)])
+def test_gemm_mid_repeatable_and_equal_to_the_other_tiled_kernels(gpu, T, N, K, act):
+    """k_gemm_mid's 4-stage ring is ordered by counted waits and one barrier per step: 30 runs are bit-identical.  And the
+    three tiled kernels add the same products in the same order (one 16x16x32 MFMA chain along K per output block), so
+    k_gemm_nt and the ping-pong kernel (debug variants 0 and 16) give the very same bits where the epilogue is the same (bias only)."""
+    torch, ffi, dev = _env()
+    g = torch.Generator(device="cpu").manual_seed(T)
+    a = torch.randn((T, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((N,), generator=g).to(dev)
+    outs = []
+    for _ in range(30):
+        y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
+        ffi.check(ffi.lib().crh_gemm_bf16_bias(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, act, 0))
+        outs.append(y)
+    torch.cuda.synchronize()
+    for y in outs[1:]:
+        assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
+    if not act:
+        y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
+        for variant in (0, 16):                               # 0: k_gemm_nt, 16: the 256x256 ping-pong kernel
+            y.fill_(0)
+            ffi.check(ffi.lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, variant, 0))
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16)), variant
+
+
 @pytest.mark.parametrize("T,K", [(1, 768), (40, 3072), (64, 768), (129, 3072), (256, 768), (257, 768), (300, 3072), (6000, 768), (22100, 3072), (23040, 768),
                                  (513, 768), (1000, 3072), (2048, 3072), (4095, 768), (4096, 3072), (16, 3072), (17, 768)])
 def test_gemm_residual_layernorm(gpu, T, K):
