@@ -165,6 +165,10 @@ class HipUniXcoder:
                 f1_w=dev(p + "intermediate.dense.weight", bf), f1_b=dev(p + "intermediate.dense.bias", f32),
                 f2_w=dev(p + "output.dense.weight", bf), f2_b=dev(p + "output.dense.bias", f32),
                 ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32)))
+        # raw addresses, taken once: a forward is 62 launches with ~10 pointer arguments each, and on the one-query path the
+        # host's enqueue time is as long as the GPU's chain of kernels
+        self._emb_ptrs = tuple(int(t.data_ptr()) for t in (self.word, self.pos, self.type0, self.emb_g, self.emb_b))
+        self._layer_ptrs = [{k: int(v.data_ptr()) for k, v in ly.items()} for ly in self.layers]
 
     # ------------------------------------------------------------------ kernels
     def forward_ids(self, ids):
@@ -182,18 +186,17 @@ class HipUniXcoder:
         hid = torch.empty((T, F), dtype=bf, device=self.device)
         kmask = torch.empty((B, (L + 63) // 64), dtype=torch.int64, device=self.device)
         sent = torch.empty((B, H), dtype=torch.float32, device=self.device)
-        p = ffi._ptr
-        ffi.check(L_.crh_embed_ln(p(ids), p(self.word), p(self.pos), p(self.type0), p(self.emb_g), p(self.emb_b), cfg.layer_norm_eps,
-                                  cfg.pad_token_id, p(x), p(kmask), B, L, H, st))
-        for ly in self.layers:
-            ffi.check(L_.crh_gemm_bf16_bias(p(x), p(ly["qkv_w"]), p(ly["qkv_b"]), p(qkv), T, 3 * H, H, 0, st))
-            ffi.check(L_.crh_attn_fwd_varlen(p(qkv), p(kmask), p(ctx), B, L, cfg.num_heads, st))
-            ffi.check(L_.crh_gemm_bf16_bias_res_ln(p(ctx), p(ly["o_w"]), p(ly["o_b"]), p(x), p(ly["ln1_g"]), p(ly["ln1_b"]),
-                                                   cfg.layer_norm_eps, p(x1), T, H, H, st))
-            ffi.check(L_.crh_gemm_bf16_bias(p(x1), p(ly["f1_w"]), p(ly["f1_b"]), p(hid), T, F, H, 1, st))
-            ffi.check(L_.crh_gemm_bf16_bias_res_ln(p(hid), p(ly["f2_w"]), p(ly["f2_b"]), p(x1), p(ly["ln2_g"]), p(ly["ln2_b"]),
-                                                   cfg.layer_norm_eps, p(x), T, H, F, st))
-        ffi.check(L_.crh_masked_mean_pool(p(x), p(kmask), p(sent), B, L, H, st))
+        px, px1, pqkv, pctx, phid, pkm, psent = (int(t.data_ptr()) for t in (x, x1, qkv, ctx, hid, kmask, sent))
+        eps, check = cfg.layer_norm_eps, ffi.check
+        gemm, gemm_ln, attn = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln, L_.crh_attn_fwd_varlen
+        check(L_.crh_embed_ln(int(ids.data_ptr()), *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, L, H, st))
+        for ly in self._layer_ptrs:
+            check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
+            check(attn(pqkv, pkm, pctx, B, L, cfg.num_heads, st))
+            check(gemm_ln(pctx, ly["o_w"], ly["o_b"], px, ly["ln1_g"], ly["ln1_b"], eps, px1, T, H, H, st))
+            check(gemm(px1, ly["f1_w"], ly["f1_b"], phid, T, F, H, 1, st))
+            check(gemm_ln(phid, ly["f2_w"], ly["f2_b"], px1, ly["ln2_g"], ly["ln2_b"], eps, px, T, H, F, st))
+        check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
         return sent
 
     # ------------------------------------------------------------------ batching
@@ -240,6 +243,8 @@ class HipUniXcoder:
             for r, i in enumerate(rows):
                 host[r, : len(id_lists[i])] = id_lists[i]
             ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+            if n == 1:                     # the query path: no scatter through a device index
+                return self.forward_ids(ids)
             out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
         return out
 
@@ -261,6 +266,8 @@ class HipUniXcoder:
                 host[r, 3:3 + b] = body_ids[i, :b]
                 host[r, 3 + b] = tok.sep_id
             ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+            if n == 1:
+                return self.forward_ids(ids)
             out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
         return out
 
