@@ -279,8 +279,9 @@ int finish_pending(crh_index *h, hipStream_t st)
 {
     if (h->pending.empty()) return CRH_OK;
     CRH_HIP(hipStreamSynchronize(st));
-    std::vector<SearchStatus> host(kStatusSlots);
-    CRH_HIP(hipMemcpy(host.data(), h->status, sizeof(SearchStatus) * kStatusSlots, hipMemcpyDeviceToHost));
+    const int used = std::max(1, std::min(h->next_slot, kStatusSlots));   // slots are handed out in order from 0
+    std::vector<SearchStatus> host((size_t)used);
+    CRH_HIP(hipMemcpy(host.data(), h->status, sizeof(SearchStatus) * (size_t)used, hipMemcpyDeviceToHost));
     std::vector<Pending> todo;
     todo.swap(h->pending);
     h->next_slot = 0;
