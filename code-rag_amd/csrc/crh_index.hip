@@ -229,8 +229,8 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
                   int64_t *out_r, int slot, hipStream_t st)
 {
     const int64_t ntiles = ceil_div(h->count, kTileRows);
-    CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
     if (ntiles == 0) {
+        CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
         const int64_t n = (int64_t)nq * k;
         hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out_s, out_r, n);
         CRH_HIP(hipGetLastError());
@@ -241,9 +241,9 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     SearchStatus *stt = h->status + slot;
 
     if (h->dtype == CRH_DTYPE_BF16)
-        hipLaunchKernelGGL(k_prep_queries<true>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
     else
-        hipLaunchKernelGGL(k_prep_queries<false>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag);
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
     CRH_HIP(hipGetLastError());
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);

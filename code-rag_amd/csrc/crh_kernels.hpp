@@ -232,11 +232,15 @@ __global__ void k_untile_rows(const u32x4 *__restrict__ xt, int ksteps, int64_t 
 // qfrag: [2][ksteps][64] u32x4 -- bf16 B-operand pieces for the scan.
 template <bool ROUND_BF16>
 __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q, int nq, int dim, int ksteps,
-                                                     float *__restrict__ qn, u32x4 *__restrict__ qfrag)
+                                                     float *__restrict__ qn, u32x4 *__restrict__ qfrag, SearchStatus *__restrict__ status)
 {
     __shared__ float qs[2048];
     __shared__ float dv_s;
     const int qi = blockIdx.x, tid = threadIdx.x;
+    if (qi == 0) {   // the batch's status slot starts from zero (first kernel of the batch: saves a memset node per search)
+        uint32_t *w = reinterpret_cast<uint32_t *>(status);
+        for (int i = tid; i < (int)(sizeof(SearchStatus) / 4); i += 64) w[i] = 0u;
+    }
     const bool real = qi < nq;
     const float *src = q + (int64_t)qi * dim;
     for (int i = tid; i < dim; i += 64) qs[i] = real ? src[i] : 0.0f;
