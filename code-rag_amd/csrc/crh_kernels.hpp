@@ -36,7 +36,7 @@ struct SearchStatus {
     unsigned int q_overflow;
     unsigned long long candidates;
     unsigned long long pad_;
-    unsigned int qcount[kMaxQ];  // per-query candidate counters of the batch (zeroed with the rest by ONE memset)
+    unsigned int qcount[kMaxQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
 };
 
 // ------------------------------------------------------------------ small helpers
