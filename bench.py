@@ -112,13 +112,12 @@ def main() -> None:
     qd = torch.from_numpy(qs).to(dev)
     row_base = rank * N
 
+    # per-rank result records [scores | rows] (ffi.topk_exchange_buffers): the exchange is ONE all-gather per step
     nslots = 4
-    out_s = [torch.empty((B, K), dtype=torch.float32, device=dev) for _ in range(nslots)]
-    out_r = [torch.empty((B, K), dtype=torch.int64, device=dev) for _ in range(nslots)]
+    slots = [ffi.topk_exchange_buffers(torch, world, B, K, dev) for _ in range(nslots)]
+    out_s, out_r = [sl[1] for sl in slots], [sl[2] for sl in slots]
     multi = dist is not None
     if multi:
-        gat_s = torch.empty((world, B, K), dtype=torch.float32, device=dev)
-        gat_r = torch.empty((world, B, K), dtype=torch.int64, device=dev)
         mer_s = torch.empty((B, K), dtype=torch.float32, device=dev)
         mer_r = torch.empty((B, K), dtype=torch.int64, device=dev)
 
@@ -132,8 +131,8 @@ def main() -> None:
         if dist is not None:
             if timed:
                 ev_x[i].record()
-            dist.all_gather_into_tensor(gat_s.view(world * B, K), s)
-            dist.all_gather_into_tensor(gat_r.view(world * B, K), r)
+            local, _, _, gathered, gat_s, gat_r = slots[i % nslots]
+            dist.all_gather_into_tensor(gathered.view(-1), local)
             ffi.merge_topk(gat_s, gat_r, mer_s, mer_r, stream)
         if timed:
             ev[i + 1].record()
@@ -233,7 +232,7 @@ def main() -> None:
                            "p90": float(np.percentile(per_step, 90))},
         "exchange_ms_device": ({"median": float(np.median(exchange)), "p10": float(np.percentile(exchange, 10)),
                                 "p90": float(np.percentile(exchange, 90)),
-                                "what": "2 RCCL all-gathers of [B,k] + k_merge_topk, rank 0"} if exchange is not None else None),
+                                "what": "1 RCCL all-gather of the [scores | rows] records + k_merge_topk, rank 0"} if exchange is not None else None),
         "search_stats": stats,
         "parity": parity,
     }

@@ -740,7 +740,16 @@ int crh_search_get_stats(crh_index *h, crh_search_stats *out)
 int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev, float *out_scores_dev,
                    int64_t *out_rows_dev, void *stream)
 {
+    return crh_merge_topk_strided(nlists, nq, k, scores_dev, rows_dev, (int64_t)nq * k, (int64_t)nq * k, out_scores_dev, out_rows_dev, stream);
+}
+
+int crh_merge_topk_strided(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev, int64_t score_list_stride,
+                           int64_t row_list_stride, float *out_scores_dev, int64_t *out_rows_dev, void *stream)
+{
     if (nlists <= 0 || nq < 0 || k <= 0) return fail(CRH_E_INVALID, "bad merge shape nlists=%d nq=%d k=%d", nlists, nq, k);
+    if (score_list_stride < (int64_t)nq * k || row_list_stride < (int64_t)nq * k)
+        return fail(CRH_E_INVALID, "merge list strides %lld / %lld are shorter than a list of %d x %d", (long long)score_list_stride,
+                    (long long)row_list_stride, nq, k);
     if (nq == 0) return CRH_OK;
     if (!scores_dev || !rows_dev || !out_scores_dev || !out_rows_dev) return fail(CRH_E_INVALID, "NULL pointer");
     const int total = nlists * k;
@@ -751,7 +760,7 @@ int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int
     static OncePerDevice once;
     if (once.need()) CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12 + 8));
     hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(1024), lds, static_cast<hipStream_t>(stream), nlists, nq, k, scores_dev, rows_dev,
-                       out_scores_dev, out_rows_dev);
+                       score_list_stride, row_list_stride, out_scores_dev, out_rows_dev);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -802,9 +802,11 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
 
 // One workgroup per query: nlists*k (score,row) pairs -> top-k by (score desc, row asc).
 // Pairs with row < 0 are padding.  total = nlists*k <= 8192.
+// List l starts at scores + l * s_stride / rows + l * r_stride (elements): nq * k for two plain [nlists, nq, k] arrays, more
+// when both live in one all-gathered buffer of [scores | rows] records per rank.
 __global__ __launch_bounds__(1024) void k_merge_topk(int nlists, int nq, int k, const float *__restrict__ scores,
-                                                      const int64_t *__restrict__ rows, float *__restrict__ out_scores,
-                                                      int64_t *__restrict__ out_rows)
+                                                      const int64_t *__restrict__ rows, int64_t s_stride, int64_t r_stride,
+                                                      float *__restrict__ out_scores, int64_t *__restrict__ out_rows)
 {
     constexpr int NT = 1024;
     extern __shared__ unsigned char smem_raw[];
@@ -817,8 +819,8 @@ __global__ __launch_bounds__(1024) void k_merge_topk(int nlists, int nq, int k, 
     for (int i = tid; i < P; i += NT) {
         if (i < total) {
             const int l = i / k, j = i % k;
-            const int64_t r = rows[((size_t)l * nq + q) * k + j];
-            ss[i] = r < 0 ? -INFINITY : scores[((size_t)l * nq + q) * k + j];
+            const int64_t r = rows[l * r_stride + (int64_t)q * k + j];
+            ss[i] = r < 0 ? -INFINITY : scores[l * s_stride + (int64_t)q * k + j];
             rr[i] = r < 0 ? INT64_MAX : r;
         } else {
             ss[i] = -INFINITY;

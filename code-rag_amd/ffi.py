@@ -25,7 +25,7 @@ EXPORTS = (
     "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_append_preprocessed", "crh_index_tombstone",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
-    "crh_merge_topk", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
+    "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_debug_gemm_variant", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_debug_read_ceiling", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
 )
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
     L.crh_index_set_profiling.argtypes = [vp, i32]
     L.crh_index_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.crh_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+    L.crh_merge_topk_strided.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, vp]
     L.crh_index_match_rows.argtypes = [vp, C.POINTER(Filter), i32, i64, vp, C.POINTER(i64)]
     L.crh_gemm_bf16_bias.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.crh_debug_gemm_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
@@ -322,11 +323,36 @@ class Index:
         return out[: int(n.value)].copy()
 
 
+def _list_stride(x, want: str, what: str, nl: int, nq: int, k: int) -> int:
+    """[nl, nq, k] device tensor whose lists are contiguous but may lie apart (views into one gathered buffer)."""
+    if str(x.dtype).rsplit(".", 1)[-1] != want:
+        raise NativeError(E_INVALID, f"{what} must be {want}, got {x.dtype}")
+    if tuple(x.shape) != (nl, nq, k) or (nq * k > 1 and (x.stride(2) != 1 or (nq > 1 and x.stride(1) != k))):
+        raise NativeError(E_INVALID, f"{what} must be [nlists, nq, k] with contiguous lists, got shape {tuple(x.shape)} strides {tuple(x.stride())}")
+    return int(x.stride(0)) if nl > 1 else nq * k
+
+
 def merge_topk(scores, rows, out_scores, out_rows, stream: int = 0) -> None:
-    """scores/rows: CUDA tensors [nlists, nq, k] (f32 / i64); out_*: [nq, k]."""
+    """scores/rows: CUDA tensors [nlists, nq, k] (f32 / i64), each list contiguous; out_*: [nq, k]."""
     nl, nq, k = (int(v) for v in scores.shape)
-    _typed(scores, "float32", "scores")
-    _out(rows, "int64", "rows", (nl, nq, k))
+    ss = _list_stride(scores, "float32", "scores", nl, nq, k)
+    rs = _list_stride(rows, "int64", "rows", nl, nq, k)
     _out(out_scores, "float32", "out_scores", (nq, k))
     _out(out_rows, "int64", "out_rows", (nq, k))
-    check(lib().crh_merge_topk(nl, nq, k, _ptr(scores), _ptr(rows), _ptr(out_scores), _ptr(out_rows), stream))
+    check(lib().crh_merge_topk_strided(nl, nq, k, _ptr(scores), _ptr(rows), ss, rs, _ptr(out_scores), _ptr(out_rows), stream))
+
+
+def topk_exchange_buffers(torch, world: int, nq: int, k: int, device):
+    """Buffers for the cross-shard exchange with ONE collective: every rank's record is [scores f32 nq*k | rows i64 nq*k]
+    (the score block padded to 8 bytes), so a single all-gather of ``local`` into ``gathered`` moves both, and the views
+    ``all_scores`` / ``all_rows`` ([world, nq, k], lists contiguous, ranks one record apart) feed merge_topk as they are.
+    Returns (local, loc_scores, loc_rows, gathered, all_scores, all_rows)."""
+    nb_s = (nq * k * 4 + 7) // 8 * 8
+    nb = nb_s + nq * k * 8
+    local = torch.empty((nb,), dtype=torch.uint8, device=device)
+    gathered = torch.empty((world, nb), dtype=torch.uint8, device=device)
+    loc_s = local[: nq * k * 4].view(torch.float32).view(nq, k)
+    loc_r = local[nb_s:].view(torch.int64).view(nq, k)
+    all_s = gathered[:, : nq * k * 4].view(torch.float32).unflatten(1, (nq, k))
+    all_r = gathered[:, nb_s:].view(torch.int64).unflatten(1, (nq, k))
+    return local, loc_s, loc_r, gathered, all_s, all_r

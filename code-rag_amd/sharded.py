@@ -73,23 +73,22 @@ class ShardedIndex:
         device path).  Returns (scores [nq,k], rows [nq,k]) -- identical on every rank; rows are global ids."""
         torch, dist = self._torch, self._dist
         nq = int(queries.shape[0])
+        # one record per rank, [scores | rows], so that ONE all-gather moves both (ffi.topk_exchange_buffers: plain torch views)
+        from . import ffi
+        local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, self.world, nq, k, self.device)
         if self._on_device:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             qd = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self.device)
-            loc_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
-            loc_r = torch.empty((nq, k), dtype=torch.int64, device=self.device)
             self.index.search(qd, k, filters=filters, row_base=self.row_base, out_scores=loc_s, out_rows=loc_r, stream=stream)
             self.index.search_finish(stream)
         else:
             s, r = self.index.search(np.asarray(queries, dtype=np.float32), k, filters=filters, row_base=self.row_base)
-            loc_s, loc_r = torch.from_numpy(np.ascontiguousarray(s)), torch.from_numpy(np.ascontiguousarray(r))
+            loc_s.copy_(torch.from_numpy(np.ascontiguousarray(s)))
+            loc_r.copy_(torch.from_numpy(np.ascontiguousarray(r)))
         if self.world == 1:
             return loc_s, loc_r
-        all_s = torch.empty((self.world, nq, k), dtype=torch.float32, device=self.device)
-        all_r = torch.empty((self.world, nq, k), dtype=torch.int64, device=self.device)
         # concatenated-along-dim-0 output form: the one every backend (RCCL and gloo) accepts
-        dist.all_gather_into_tensor(all_s.view(self.world * nq, k), loc_s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(all_r.view(self.world * nq, k), loc_r.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(gathered.view(-1), local, group=self.group)
         out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         out_r = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if self._on_device:

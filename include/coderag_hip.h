@@ -159,6 +159,11 @@ int crh_debug_read_ceiling(crh_index *h, void *stream);
  * (does not exist in the reference). */
 int crh_merge_topk(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev,
                    float *out_scores_dev, int64_t *out_rows_dev, void *stream);
+/* Same, with list l at scores_dev + l * score_list_stride and rows_dev + l * row_list_stride (elements, each >= nq * k): lets
+ * every rank send ONE [scores | rows] record through ONE all-gather and merge straight out of the gathered buffer. */
+int crh_merge_topk_strided(int nlists, int nq, int k, const float *scores_dev, const int64_t *rows_dev,
+                           int64_t score_list_stride, int64_t row_list_stride, float *out_scores_dev,
+                           int64_t *out_rows_dev, void *stream);
 
 /* ---- hybrid re-rank of the vector branch (BASELINE config 5; replaces, for vector-only candidate lists, the per-query
  * host loop of HybridRanker.rank_results, src/lattice/query/ranking/ranker.py:24-54 + scorer.py:80-126 + ranker.py:171-229).

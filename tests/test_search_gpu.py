@@ -402,3 +402,32 @@ def test_merge_topk_large_lists(gpu, nlists, k):
     with pytest.raises(ffi.NativeError):
         ffi.merge_topk(torch.zeros((9, 1, 1000), dtype=torch.float32, device=dev), torch.zeros((9, 1, 1000), dtype=torch.int64, device=dev),
                        torch.empty((1, 1000), dtype=torch.float32, device=dev), torch.empty((1, 1000), dtype=torch.int64, device=dev), 0)
+
+
+@pytest.mark.parametrize("world,nq,k", [(3, 5, 7), (8, 64, 100), (2, 1, 1)])
+def test_merge_out_of_the_packed_exchange_buffer(gpu, world, nq, k):
+    """The one-collective exchange: every rank's record is [scores | rows]; merge_topk reads the lists in place out of the
+    gathered buffer (list strides of one record), same result as merging two plain arrays and as the oracle."""
+    import torch
+    ffi = _ffi()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(world * 100 + k)
+    s = -np.sort(-rng.standard_normal((world, nq, k)).astype(np.float32), axis=2)
+    r = rng.permutation(world * nq * k).astype(np.int64).reshape(world, nq, k)
+    local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, world, nq, k, dev)
+    assert loc_s.is_contiguous() and loc_r.is_contiguous() and loc_r.data_ptr() % 8 == 0
+    for w in range(world):                                   # what the all-gather does: record w = rank w's local buffer
+        loc_s.copy_(torch.from_numpy(s[w]))
+        loc_r.copy_(torch.from_numpy(r[w]))
+        gathered[w].copy_(local)
+    ms, mr = torch.empty((nq, k), dtype=torch.float32, device=dev), torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ffi.merge_topk(all_s, all_r, ms, mr, 0)
+    ps, pr = torch.empty_like(ms), torch.empty_like(mr)
+    ffi.merge_topk(torch.from_numpy(s).to(dev), torch.from_numpy(r).to(dev), ps, pr, 0)
+    torch.cuda.synchronize()
+    es, er = orc.merge_topk(s, r)
+    assert np.array_equal(mr.cpu().numpy(), er) and np.array_equal(ms.cpu().numpy(), es)
+    assert torch.equal(ms, ps) and torch.equal(mr, pr)
+    if nq > 1 and k > 1:
+        with pytest.raises(ffi.NativeError):                 # lists that are not contiguous are refused, not misread
+            ffi.merge_topk(all_s.transpose(1, 2), all_r, ms, mr, 0)
