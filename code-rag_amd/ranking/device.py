@@ -120,17 +120,28 @@ class SideColumns:
         t = self._torch
         dev = self._resident()
         n = int(rows_dev.numel())
-        out = {}
+        # all columns are views of ONE int32 buffer ([n] per integer column, then 64 name bytes = 16 words per candidate), so
+        # that a sharded caller completes the table with one all-reduce of ``out.packed`` (sharded.gather_columns)
+        words = ffi.RR_NAME_BYTES // 4
+        buf = t.empty((n * (len(self.INT_COLS) + words),), dtype=t.int32, device=self.device)
+        out = PackedColumns()
+        out.packed = buf
         L = ffi.lib()
-        for c in self.INT_COLS:
-            o = t.empty((n,), dtype=t.int32, device=self.device)
+        for i, c in enumerate(self.INT_COLS):
+            o = buf[i * n:(i + 1) * n]
             ffi.check(L.crh_gather_rows_i32(n, rows_dev.data_ptr(), row_base, self.rows, dev[c].data_ptr(), 0, o.data_ptr(), stream))
             out[c] = o
-        o = t.empty((n, ffi.RR_NAME_BYTES), dtype=t.uint8, device=self.device)
+        o = buf[len(self.INT_COLS) * n:].view(t.uint8).view(n, ffi.RR_NAME_BYTES)
         ffi.check(L.crh_gather_rows_bytes(n, rows_dev.data_ptr(), row_base, self.rows, dev["name"].data_ptr(), ffi.RR_NAME_BYTES,
                                           o.data_ptr(), stream))
         out["name"] = o
         return out
+
+
+class PackedColumns(dict):
+    """Column name -> tensor, all of them views of ``packed`` (one int32 buffer).  At most one shard contributes a non-zero
+    value per element, so summing the buffers of all shards word by word completes every column, the name bytes included."""
+    packed: Any = None
 
 
 @dataclass

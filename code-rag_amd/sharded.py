@@ -108,12 +108,16 @@ class ShardedIndex:
 
     def gather_columns(self, rows) -> dict[str, Any]:
         """Side data of a merged candidate table (global rows, identical on every rank): every rank gathers the rows it
-        owns (the others give zeros) and one all-reduce(sum) per column completes the table on all ranks -- [nq, k] small
-        integers plus 64 name bytes per candidate, ~0.6 MB at nq=64, k=100."""
+        owns (the others give zeros) and ONE all-reduce(sum) of the packed buffer completes the table on all ranks -- [nq, k]
+        small integers plus 64 name bytes per candidate, ~0.6 MB at nq=64, k=100 (one all-reduce per column for a plain dict)."""
         cols = self.side.gather(rows, row_base=self.row_base)
         if self.world > 1:
-            for name in cols:
-                self._dist.all_reduce(cols[name], op=self._dist.ReduceOp.SUM, group=self.group)
+            packed = getattr(cols, "packed", None)
+            if packed is not None:      # every column is a view of one buffer (ranking.device.PackedColumns): one collective
+                self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self.group)
+            else:
+                for name in cols:
+                    self._dist.all_reduce(cols[name], op=self._dist.ReduceOp.SUM, group=self.group)
         return cols
 
     def search_rerank(self, queries, k: int, plans, reranker, filters=None):

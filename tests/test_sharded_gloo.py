@@ -70,14 +70,29 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             glob = rows_t.numpy().reshape(-1)
             val = np.where(own, (glob % 1000) * 3 + 1, 0).astype(np.int32)          # a function of the GLOBAL row id
             name = np.where(own[:, None], (glob[:, None] + np.arange(4)[None, :]) % 251, 0).astype(np.uint8)
-            return {"content_len": torch.from_numpy(val), "name": torch.from_numpy(name)}
+            if not self.packed:
+                return {"content_len": torch.from_numpy(val), "name": torch.from_numpy(name)}
+            # the device form (ranking.device.PackedColumns): every column a view of one int32 buffer, one all-reduce
+            from coderag_amd.ranking.device import PackedColumns
+            n = len(val)
+            buf = torch.zeros((2 * n,), dtype=torch.int32)
+            out = PackedColumns()
+            out.packed = buf
+            out["content_len"] = buf[:n]
+            out["name"] = buf[n:].view(torch.uint8).view(n, 4)
+            out["content_len"].copy_(torch.from_numpy(val))
+            out["name"].copy_(torch.from_numpy(name))
+            return out
 
-    sh.attach_side_columns(FakeSide(counts[rank]))
-    s, rows = sh.search(q, 10)
-    cols = sh.gather_columns(rows)
-    flat = rows.numpy().reshape(-1)
-    assert np.array_equal(cols["content_len"].numpy(), ((flat % 1000) * 3 + 1).astype(np.int32)), f"rank {rank}: column not completed"
-    assert np.array_equal(cols["name"].numpy(), ((flat[:, None] + np.arange(4)[None, :]) % 251).astype(np.uint8))
+    for packed in (False, True):
+        side = FakeSide(counts[rank])
+        side.packed = packed
+        sh.attach_side_columns(side)
+        s, rows = sh.search(q, 10)
+        cols = sh.gather_columns(rows)
+        flat = rows.numpy().reshape(-1)
+        assert np.array_equal(cols["content_len"].numpy(), ((flat % 1000) * 3 + 1).astype(np.int32)), f"rank {rank}: column not completed"
+        assert np.array_equal(cols["name"].numpy(), ((flat[:, None] + np.arange(4)[None, :]) % 251).astype(np.uint8))
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     dist.destroy_process_group()
 
