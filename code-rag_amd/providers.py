@@ -17,6 +17,7 @@ import asyncio
 import logging
 import os
 from abc import ABC, abstractmethod
+from collections import deque
 from collections.abc import Sequence
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
@@ -137,7 +138,7 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
         # "list" (default): list[list[float]] exactly as the reference's providers return; "numpy": list of float32 arrays --
         # what a store that converts to an array anyway (Qdrant's client does, HipVectorStore does) takes several times faster
         self.vector_rows = str(config.extra.get("vector_rows", "list"))
-        self._pending: list[tuple[list[str], asyncio.Future]] = []
+        self._pending: deque[tuple[list[str], asyncio.Future]] = deque()
         self._drainer: asyncio.Task | None = None
         self.submissions = 0                       # GPU submissions so far (observability / tests)
         logger.info("Initializing HIP UniXcoder embedding provider...")
@@ -159,7 +160,7 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
             raise EmbeddingError("HIP UniXcoder embedding failed", cause=e)
 
     async def _embed_impl(self, texts: list[str]) -> list[list[float]]:
-        loop = asyncio.get_event_loop()
+        loop = asyncio.get_running_loop()
         if not self.dynamic_batching:
             self.submissions += 1
             return await loop.run_in_executor(self._executor, self._embed_sync, list(texts))
@@ -172,12 +173,12 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
     async def _drain(self) -> None:
         """Collect what arrives within the window (or until max_batch_texts), embed it in one submission, hand each caller
         its slice back in order.  A failure is delivered to every caller of that submission (each then retries on its own)."""
-        loop = asyncio.get_event_loop()
+        loop = asyncio.get_running_loop()
         while self._pending:
             await asyncio.sleep(self.batch_window_s)
             batch, count = [], 0
             while self._pending and (not batch or count + len(self._pending[0][0]) <= self.max_batch_texts):
-                item = self._pending.pop(0)
+                item = self._pending.popleft()
                 batch.append(item)
                 count += len(item[0])
             flat = [t for texts, _ in batch for t in texts]
