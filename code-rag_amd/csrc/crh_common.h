@@ -70,4 +70,19 @@ struct OncePerDevice {
     }
 };
 
+// CU count of the CURRENT device, looked up once per device (a process-wide static would hand device 0's count to a
+// launch on another device of a mixed node).
+inline int current_device_cus()
+{
+    static int cus[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 256;
+    d &= 63;
+    if (!cus[d]) {
+        hipDeviceProp_t prop;
+        cus[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount >= 8) ? prop.multiProcessorCount : 256;
+    }
+    return cus[d];
+}
+
 }  // namespace crh

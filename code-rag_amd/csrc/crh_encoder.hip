@@ -967,16 +967,12 @@ unsigned xcd_grid(int64_t panels, int64_t nb, int64_t max_per_label)
 }
 unsigned gemm_grid(int T, int N)
 {
-    static int cus = 0, persistent = -1;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus < 8) cus = 256;
+    static int persistent = -1;
+    if (persistent < 0) {
         const char *e = getenv("CODERAG_HIP_GEMM_PERSISTENT");
         persistent = (e && e[0] == '0') ? 0 : 1;
     }
-    return xcd_grid(crh::ceil_div(T, BM), N / BN, persistent ? cus / 8 : INT32_MAX);
+    return xcd_grid(crh::ceil_div(T, BM), N / BN, persistent ? crh::current_device_cus() / 8 : INT32_MAX);
 }
 
 // T <= 16 rows (one very short query): k_gemm_skinny; from 17 rows on k_gemm_mid is faster (tools/enc_mid_bench.py: one
@@ -1042,15 +1038,7 @@ GemmKernel choose_gemm(int T, int N, int K, int act)
 }
 unsigned gemm256_grid(int T, int N)
 {
-    int cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    static int cached = 0;
-    if (!cached) {
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
-            cus = prop.multiProcessorCount;
-        cached = cus;
-    }
-    return xcd_grid(crh::ceil_div(T, g256::BM), N / g256::BN, cached / 8);
+    return xcd_grid(crh::ceil_div(T, g256::BM), N / g256::BN, crh::current_device_cus() / 8);
 }
 int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
 {
@@ -1116,6 +1104,7 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
     return CRH_OK;
 }
 
+#ifdef CRH_ENABLE_DEBUG   // libcoderag_hip_debug.so only (build.sh): never exported by the product library
 // timing ablations of the GEMM main loop (tools/gemm_ablate.py); results are meaningless for variant != 0
 int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K, int variant, void *stream)
 {
@@ -1172,6 +1161,7 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
+#endif  // CRH_ENABLE_DEBUG
 
 int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual, const float *gamma,
                               const float *beta, float eps, void *y, int T, int N, int K, void *stream)

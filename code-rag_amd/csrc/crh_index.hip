@@ -602,6 +602,7 @@ int crh_index_read_rows(crh_index *h, int64_t first, int64_t n, float *out_host)
     return CRH_OK;
 }
 
+#ifdef CRH_ENABLE_DEBUG   // libcoderag_hip_debug.so only
 int crh_debug_read_ceiling(crh_index *h, void *stream)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
@@ -613,6 +614,7 @@ int crh_debug_read_ceiling(crh_index *h, void *stream)
     CRH_TRY(build_mask(h, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
     return launch_scan<2>(h, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, h->ws_wave_cap, h->ws_qcap, h->status);
 }
+#endif  // CRH_ENABLE_DEBUG
 
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
 {

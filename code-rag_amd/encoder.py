@@ -174,6 +174,7 @@ class HipUniXcoder:
     def forward_ids(self, ids):
         """ids: int32 CUDA tensor [B, L], L % 16 == 0, padded with the pad id.  Returns f32 [B, 768] sentence embeddings."""
         torch, L_ = self._torch, ffi.lib()
+        ffi.use_device(self.device.index)      # (worker threads start on device 0)
         B, L = ids.shape
         cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
         T = B * L

@@ -26,9 +26,12 @@ EXPORTS = (
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
-    "crh_gemm_bf16_bias", "crh_debug_gemm_variant", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
-    "crh_masked_mean_pool", "crh_debug_read_ceiling", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
+    "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
+    "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
 )
+# exported by lib/libcoderag_hip_debug.so only (same sources built with -DCRH_ENABLE_DEBUG; tools/ and kernel tests)
+DEBUG_EXPORTS = ("crh_debug_gemm_variant", "crh_debug_read_ceiling")
+DEBUG_LIB_PATH = Path(os.environ.get("CODERAG_HIP_DEBUG_LIB", PKG_DIR / "lib" / "libcoderag_hip_debug.so"))
 
 RR_NAME_BYTES, RR_MAX_ENTITIES, RR_ENTITY_BYTES = 64, 8, 48
 
@@ -64,6 +67,7 @@ class SearchStats(C.Structure):
 
 
 _lib = None
+_debug_lib = None
 
 
 def _preload_hip_runtime() -> None:
@@ -87,13 +91,26 @@ def _preload_hip_runtime() -> None:
 def lib() -> C.CDLL:
     """Load the native library once; raise loudly when it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
-        raise NativeError(E_INTERNAL, f"{LIB_PATH} is missing -- build it with "
+    if _lib is None:
+        _lib = _bind(LIB_PATH, debug=False)
+    return _lib
+
+
+def debug_lib() -> C.CDLL:
+    """``libcoderag_hip_debug.so``: the product's sources + the ``crh_debug_*`` entry points.  For tools/ and kernel tests
+    only -- nothing in the package calls this.  It is a separate library instance (its own handles and error slot)."""
+    global _debug_lib
+    if _debug_lib is None:
+        _debug_lib = _bind(DEBUG_LIB_PATH, debug=True)
+    return _debug_lib
+
+
+def _bind(path: Path, debug: bool) -> C.CDLL:
+    if not path.exists():
+        raise NativeError(E_INTERNAL, f"{path} is missing -- build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
     _preload_hip_runtime()
-    L = C.CDLL(str(LIB_PATH))
+    L = C.CDLL(str(path))
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     L.crh_abi_version.restype = i32
     L.crh_last_error.restype = C.c_char_p
@@ -118,27 +135,43 @@ def lib() -> C.CDLL:
     L.crh_merge_topk_strided.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, vp]
     L.crh_index_match_rows.argtypes = [vp, C.POINTER(Filter), i32, i64, vp, C.POINTER(i64)]
     L.crh_gemm_bf16_bias.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.crh_debug_gemm_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.crh_gemm_bf16_bias_res_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, vp]
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    L.crh_debug_read_ceiling.argtypes = [vp, vp]
     L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]
-    for name in EXPORTS:
+    if debug or hasattr(L, "crh_debug_gemm_variant"):   # (CODERAG_HIP_LIB may point a tool's whole run at the debug build)
+        debug = True
+        L.crh_debug_gemm_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.crh_debug_read_ceiling.argtypes = [vp, vp]
+    for name in EXPORTS + (DEBUG_EXPORTS if debug else ()):
         if name != "crh_last_error":
             getattr(L, name).restype = i32
     if L.crh_abi_version() != 1:
-        raise NativeError(E_INTERNAL, "ABI version mismatch between ffi.py and libcoderag_hip.so")
-    _lib = L
+        raise NativeError(E_INTERNAL, f"ABI version mismatch between ffi.py and {path.name}")
     return L
 
 
-def check(rc: int) -> None:
+def check(rc: int, L: C.CDLL | None = None) -> None:
     if rc != OK:
-        raise NativeError(rc, (lib().crh_last_error() or b"").decode("utf-8", "replace"))
+        raise NativeError(rc, ((L or lib()).crh_last_error() or b"").decode("utf-8", "replace"))
+
+
+def use_device(device: int) -> None:
+    """Make ``device`` the calling thread's current HIP device.  The stateless entry points (GEMMs, attention, merge, gather,
+    re-rank) launch on the CURRENT device, and a worker thread (the provider's and the store's executors) starts on device 0
+    whatever the thread that created the tensors had selected."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.current_device() != int(device):   # (no device: the native call that follows reports it)
+        torch.cuda.set_device(int(device))
+
+
+def current_stream(device) -> int:
+    """torch's current stream on ``device`` as a raw hipStream_t."""
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)
 
 
 def device_count() -> int:
@@ -335,6 +368,7 @@ def _list_stride(x, want: str, what: str, nl: int, nq: int, k: int) -> int:
 def merge_topk(scores, rows, out_scores, out_rows, stream: int = 0) -> None:
     """scores/rows: CUDA tensors [nlists, nq, k] (f32 / i64), each list contiguous; out_*: [nq, k]."""
     nl, nq, k = (int(v) for v in scores.shape)
+    use_device(scores.device.index)
     ss = _list_stride(scores, "float32", "scores", nl, nq, k)
     rs = _list_stride(rows, "int64", "rows", nl, nq, k)
     _out(out_scores, "float32", "out_scores", (nq, k))

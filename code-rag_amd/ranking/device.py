@@ -114,10 +114,13 @@ class SideColumns:
             self._dev = dev
         return self._dev
 
-    def gather(self, rows_dev, row_base: int = 0, stream: int = 0) -> dict[str, Any]:
+    def gather(self, rows_dev, row_base: int = 0, stream: int | None = None) -> dict[str, Any]:
         """Side data of a candidate table ``rows_dev`` (int64 CUDA tensor [nq, k]); rows of other shards give zeros
-        (degree: 0 as well, so that the shards' gathers add up -- the owner contributes the real value)."""
+        (degree: 0 as well, so that the shards' gathers add up -- the owner contributes the real value).
+        ``stream=None``: torch's current stream on this device (where ``rows_dev`` was produced)."""
         t = self._torch
+        ffi.use_device(self.device.index)
+        stream = ffi.current_stream(self.device) if stream is None else stream
         dev = self._resident()
         n = int(rows_dev.numel())
         # all columns are views of ONE int32 buffer ([n] per integer column, then 64 name bytes = 16 words per candidate), so
@@ -184,8 +187,10 @@ class DeviceReranker:
         self.centrality_top = centrality_top   # QueryEngine looks up the first 5 vector hits (engine.py:358-362)
         self.device = torch.device("cuda", device)
 
-    def rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int = 0) -> RerankOutput:
+    def rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None) -> RerankOutput:
         t = self._torch
+        ffi.use_device(self.device.index)
+        stream = ffi.current_stream(self.device) if stream is None else stream
         nq, k = (int(v) for v in scores_dev.shape)
         if len(plans) != nq:
             raise ValueError(f"{len(plans)} plans for {nq} candidate lists")

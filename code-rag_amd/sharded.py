@@ -77,6 +77,7 @@ class ShardedIndex:
         from . import ffi
         local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, self.world, nq, k, self.device)
         if self._on_device:
+            ffi.use_device(self.device.index)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             qd = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self.device)
             self.index.search(qd, k, filters=filters, row_base=self.row_base, out_scores=loc_s, out_rows=loc_r, stream=stream)

@@ -303,6 +303,7 @@ class HipVectorStore:
 
         def guarded():
             with self._lock:
+                ffi.use_device(self._device)      # the worker thread starts on device 0 whatever CODERAG_HIP_DEVICE says
                 return fn(*args)
         return await loop.run_in_executor(self._executor, guarded)
 

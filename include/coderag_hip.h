@@ -149,10 +149,6 @@ int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_lau
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
 
-/* Measurement support: launches the main scan's loads alone (same grid, same tile walk, same nt loads; no MFMA, no
- * candidates) over the whole corpus -- the HBM read rate this access pattern reaches on the device at hand, the ceiling
- * the scan's achieved GB/s is to be read against (tools/read_ceiling.py). */
-int crh_debug_read_ceiling(crh_index *h, void *stream);
 
 /* Merge nlists sorted per-shard lists ([nlists, nq, k] device f32 / int64, padded with
  * (-inf,-1)) into [nq, k]: the step after the all-gather of a row-sharded search
@@ -231,11 +227,6 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
 int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
                        int act, void *stream);
 
-/* Timing ablations of the GEMM main loop (variant 0 = the real kernel; others skip a pipeline stage and return
- * garbage).  Development aid used by tools/gemm_ablate.py; not part of the product path. */
-int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
-                           int variant, void *stream);
-
 /* y[T, N] = LayerNorm(x @ w^T + bias + residual) * gamma + beta  (post-LN block end). N == 768. */
 int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual,
                               const float *gamma, const float *beta, float eps, void *y, int T, int N,
@@ -258,6 +249,21 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
 /* sent[b, :] = sum over real tokens of tok[b, t, :] / #real tokens  (f32 out, no L2 normalisation). */
 int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D,
                          void *stream);
+
+/* ------------------------------------------------------------- debug build only --------- */
+/* Exported ONLY by libcoderag_hip_debug.so (code-rag_amd/build.sh compiles the same sources a second time with
+ * -DCRH_ENABLE_DEBUG for tools/ and the kernel-selection tests); the product library has no crh_debug_* symbol. */
+#ifdef CRH_ENABLE_DEBUG
+/* Measurement support: launches the main scan's loads alone (same grid, same tile walk, same nt loads; no MFMA, no
+ * candidates) over the whole corpus -- the HBM read rate this access pattern reaches on the device at hand, the ceiling
+ * the scan's achieved GB/s is to be read against (tools/read_ceiling.py). */
+int crh_debug_read_ceiling(crh_index *h, void *stream);
+
+/* Timing ablations of the GEMM main loop (variant 0 = the real kernel; others skip a pipeline stage and return
+ * garbage).  Development aid used by tools/gemm_ablate.py; not part of the product path. */
+int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
+                           int variant, void *stream);
+#endif /* CRH_ENABLE_DEBUG */
 
 #ifdef __cplusplus
 }

@@ -8,10 +8,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(debug: bool = False):
+    """Entry points the header declares: the product part, or the part inside `#ifdef CRH_ENABLE_DEBUG`."""
     text = open(os.path.join(ROOT, "include", "coderag_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(crh_[a-z0-9_]+)\s*\(", text)))
+    a, b = text.index("#ifdef CRH_ENABLE_DEBUG"), text.index("#endif", text.index("#ifdef CRH_ENABLE_DEBUG"))
+    part = text[a:b] if debug else text[:a] + text[b:]
+    return sorted(set(re.findall(r"\b(crh_[a-z0-9_]+)\s*\(", part)))
 
 
 def test_header_and_binding_agree():
@@ -27,6 +30,23 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
     assert lib.crh_abi_version() == 1
+
+
+def test_product_library_exports_no_debug_entry_point():
+    """crh_debug_* (timing ablations, kernel-selection overrides) live in libcoderag_hip_debug.so only."""
+    import subprocess
+    import coderag_amd  # noqa: F401
+    from coderag_amd import ffi
+    assert declared_symbols(debug=True) == sorted(ffi.DEBUG_EXPORTS) and all(n.startswith("crh_debug_") for n in ffi.DEBUG_EXPORTS)
+    names = subprocess.check_output(["nm", "-D", "--defined-only", str(ffi.LIB_PATH)]).decode()
+    assert "crh_debug_" not in names
+    exported = sorted(set(re.findall(r"\b(crh_[a-z0-9_]+)\b", names)))
+    assert exported == declared_symbols(), "the product library exports exactly what the header declares"
+    dbg = ffi.debug_lib()
+    for name in declared_symbols() + declared_symbols(debug=True):
+        assert hasattr(dbg, name)
+    src = "".join(open(os.path.join(dp, f)).read() for dp, _, fs in os.walk(os.path.join(ROOT, "code-rag_amd")) for f in fs if f.endswith(".py") and f != "ffi.py")
+    assert "debug_lib" not in src and "crh_debug" not in src, "the package itself must not reach for the debug build"
 
 
 def test_calls_fail_loudly_without_a_device():

@@ -77,7 +77,7 @@ def test_gemm256_small_and_ragged(gpu, T, N, K):
     w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
     b = torch.randn((N,), generator=g).to(dev)
     y = torch.full((T + 8, N), 7.0, dtype=torch.bfloat16, device=dev)     # 8 guard rows: nothing may be written past T
-    ffi.check(ffi.lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, 16, 0))
+    ffi.check(ffi.debug_lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, 16, 0))
     ref = a.float() @ w.float().T + b
     torch.cuda.synchronize()
     _close(torch, y[:T], ref, rel=2 ** -7, abs_=2e-3)
@@ -127,7 +127,7 @@ def test_gemm_mid_repeatable_and_equal_to_the_other_tiled_kernels(gpu, T, N, K, 
         y = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
         for variant in (0, 16):                               # 0: k_gemm_nt, 16: the 256x256 ping-pong kernel
             y.fill_(0)
-            ffi.check(ffi.lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, variant, 0))
+            ffi.check(ffi.debug_lib().crh_debug_gemm_variant(a.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), T, N, K, variant, 0))
             torch.cuda.synchronize()
             assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16)), variant
 

@@ -6,7 +6,7 @@ import torch
 import coderag_amd  # noqa: F401
 from coderag_amd import ffi
 
-L = ffi.lib()
+L = ffi.debug_lib()
 dev = torch.device("cuda:0")
 for (T, N, K) in ((32768, 2304, 768), (32768, 768, 3072)):
     a = torch.randn((T, K), device=dev).to(torch.bfloat16)

@@ -10,7 +10,7 @@ from coderag_amd import ffi
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 VARIANTS = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 16]
 dev = torch.device("cuda:0")
-L = ffi.lib()
+L = ffi.debug_lib()
 shapes = [("qkv", 2304, 768), ("oproj", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)]
 g = torch.Generator(device="cpu").manual_seed(1)
 for name, N, K in shapes:

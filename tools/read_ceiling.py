@@ -4,6 +4,8 @@ python tools/read_ceiling.py [rows]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+# the probe entry point exists in the debug build only: this tool's whole run (index, scan, probe) uses that library
+os.environ.setdefault("CODERAG_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "code-rag_amd", "lib", "libcoderag_hip_debug.so"))
 import coderag_amd
 from coderag_amd import ffi
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
