@@ -84,19 +84,28 @@ __global__ __launch_bounds__(256) void k_rerank_vector(RerankArgs a)
     const crh_rerank_query &Q = a.queries[q];
     const size_t base = (size_t)q * k;
     if (tid == 0) {
+        int need_host_early = 0;
         // centrality table as engine.py:348-377 builds it for a vector-only query: the first `centrality_top` hits that
         // carry an entity name are looked up under (graph_node_id or entity_name); a lookup the graph could not answer
         // (degree < 0) leaves no entry
         int n = 0;
         for (int i = 0; i < k && i < a.centrality_top; ++i) {
             if (a.rows[base + i] < 0 || a.cols.name_len[base + i] <= 0) continue;
-            if (a.cols.degree[base + i] < 0 || n >= 16) continue;
-            tab_node[n] = a.cols.node_code[base + i];
+            if (a.cols.degree[base + i] < 0) continue;
+            const int node = a.cols.node_code[base + i];
+            bool seen = false;                                  // the engine collects the names in a set: one lookup per key
+            for (int t = 0; t < n; ++t) seen = seen || tab_node[t] == node;
+            if (seen) continue;
+            if (n >= 16) {                                      // more distinct keys than the table holds: the host decides
+                need_host_early = 1;
+                break;
+            }
+            tab_node[n] = node;
             tab_deg[n] = a.cols.degree[base + i];
             ++n;
         }
         tab_n = n;
-        need_host = (Q.n_entities < 0 || Q.n_entities > CRH_RR_MAX_ENTITIES) ? 1 : 0;
+        need_host = (need_host_early || Q.n_entities < 0 || Q.n_entities > CRH_RR_MAX_ENTITIES) ? 1 : 0;
     }
     __syncthreads();
 

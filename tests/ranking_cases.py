@@ -47,3 +47,38 @@ def scenario(i):
 
 def scenarios():
     return [scenario(i) for i in range(N_SCENARIOS)]
+
+
+# ---- vector-only scenarios (no graph context): what the DEVICE re-rank (crh_rerank_vector) decides.  Expected outputs in
+# tests/golden/ranking_vector_only_reference.json come from the reference's own ranker (tests/golden/gen_vector_only_goldens.py).
+N_VECTOR_ONLY, VSEED = 120, 20261004
+VNAMES = NAMES + ["UserRepository.save", "Parser.parse_file", "parse_file", "a_very_long_entity_name_that_is_still_below_the_sixty_four_bytes",
+                  "Config.load", "löwe_ß", "do", "Helper", "helper"]
+
+
+def _vhit(rng, score, files):
+    name = rng.choice(VNAMES)
+    line = rng.choice([1, 1, 10, 20, 30])
+    n = rng.choice([0, 10, 50, 51, 60, 100, 101, 150, 1999, 2000, 2500, 2999, 3000, 4000])
+    # a hit without a name is never looked up by the engine (engine.py:358-360): it carries no graph node id here either
+    gid = rng.choice([None, name, "app." + name]) if name else None
+    return dict(score=score, file_path=rng.choice(files), entity_type=rng.choice(["function", "class", "method", "file"]), entity_name=name,
+                language=rng.choice(["python", "typescript"]), content=("x" * n) if n else rng.choice([None, ""]), start_line=line,
+                end_line=line + 5, graph_node_id=gid, summary=rng.choice([None, "S"]))
+
+
+def vector_only_scenario(i):
+    """Hit lists as a store returns them (descending score, exact ties included), 1..128 hits, small pools of names / files /
+    lines so merge keys collide (-> "hybrid"), files repeat past the per-file cap, and the total passes the cap of 50."""
+    rng = random.Random(VSEED * 1000 + i)
+    n_hits = rng.choice([1, 2, 5, 12, 20, 37, 64, 100, 128])
+    # multiples of 2^-12: exactly representable in f32, so the device (f32 hit scores) and the reference (Python floats) start
+    # from the same numbers and every f64 result can be compared to the last bit
+    scores = sorted((rng.choice([0.5, 0.75, rng.randrange(-800, 4056) / 4096.0]) for _ in range(n_hits)), reverse=True)
+    keys = [n for n in VNAMES if n] + ["app." + n for n in VNAMES if n]
+    cent = {k: {"in_degree": (d := rng.randrange(0, 80)), "out_degree": (o := rng.randrange(0, 80)), "total_degree": d + o, "relationship_count": d + o}
+            for k in rng.sample(keys, rng.randrange(0, 9))}
+    ents = rng.sample([n for n in VNAMES if n] + ["USERREPOSITORY", "pars", "Parse", "zzz", "", "LÖWE_ß"], rng.randrange(0, 5))
+    files = FILES if rng.random() < 0.5 else FILES + [f"pkg/m{j}.py" for j in range(17)]      # 7 files x 5 = 35 < the total cap of 50 < 24 x 5
+    return dict(name=f"vector_only_{i}", intent=rng.choice(INTENTS), entities=ents, graph={},
+                vector=[_vhit(rng, s, files) for s in scores], centrality=rng.choice([cent, cent, cent, None]))

@@ -128,3 +128,39 @@ async def run_store_scenarios(s):
         raise AssertionError("closed store must not hand out a client")
     except VectorStoreError:
         pass
+
+
+async def run_reference_database_scenario(manager, CollectionName):
+    """The ONE result-pinning scenario the reference holds at the store boundary, re-expressed literally
+    (/root/reference/tests/test_database.py:64-124, TestQdrantConnection: connect + health, create_collections + names,
+    upsert `[0.1]*1536` with entity_name "test_func", search the same vector, >= 1 hit with that name, delete by file_path).
+    `manager` is constructed as the reference constructs QdrantManager(): no arguments beyond the store's own dim default."""
+    import uuid
+    await manager.connect()
+    assert await manager.health_check(), "Qdrant should be healthy"
+    await manager.close()
+
+    async with manager:
+        await manager.create_collections()
+        collections = await manager.client.get_collections()
+        collection_names = [c.name for c in collections.collections]
+        assert CollectionName.CODE_CHUNKS.value in collection_names
+        assert CollectionName.SUMMARIES.value in collection_names
+
+    async with manager:
+        await manager.create_collections()
+        test_vector = [0.1] * 1536
+        test_id = str(uuid.uuid4())
+        test_payload = {"file_path": "/test/file.py", "entity_type": "function", "entity_name": "test_func", "language": "python",
+                        "content": "def test(): pass"}
+        await manager.upsert(collection=CollectionName.CODE_CHUNKS.value, ids=[test_id], vectors=[test_vector], payloads=[test_payload])
+        results = await manager.search(collection=CollectionName.CODE_CHUNKS.value, query_vector=test_vector, limit=1)
+        assert len(results) >= 1
+        assert results[0]["payload"]["entity_name"] == "test_func"
+        # beyond what the reference asserts: the id and the payload come back whole, and the score is the oracle's cosine of the
+        # vector with itself under Qdrant's preprocess (1.0 up to f32 rounding of 1536 equal terms)
+        assert results[0]["id"] == test_id and results[0]["payload"] == test_payload
+        es, _ = orc.cosine_search(np.asarray([test_vector], np.float32), np.asarray([test_vector], np.float32), 1)
+        assert results[0]["score"] == float(es[0, 0]) and abs(results[0]["score"] - 1.0) < 2e-4     # sequential f32 sum of 1536 equal terms: 0.99996
+        await manager.delete(collection=CollectionName.CODE_CHUNKS.value, filters={"file_path": "/test/file.py"})
+        assert await manager.search(collection=CollectionName.CODE_CHUNKS.value, query_vector=test_vector, limit=1) == []

@@ -75,3 +75,29 @@ def test_ranker_matches_reference_on_random_scenarios(case):
     head = [[r["entity_name"], r["file_path"], r["start_line"], r["source"], r["final_score"]] for r in got["ranked"][:4]]
     assert (len(got["ranked"]), head) == (case["n"], case["head"])
     assert hashlib.sha1(json.dumps(got, sort_keys=True).encode()).hexdigest() == case["digest"]     # every field of every result
+
+
+# ---- 120 seeded vector-only scenarios (what the device re-rank decides); expected rows from the reference's ranker
+VO_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_vector_only_reference.json")))
+VO_SIGNALS = ("vector_similarity", "query_entity_match", "centrality", "code_quality")
+
+
+def vector_only_rows(ranked):
+    return [[r.entity_name, r.file_path, r.start_line, getattr(r.source, "value", r.source), r.final_score] + [r.signal_scores.get(s) for s in VO_SIGNALS]
+            for r in ranked]
+
+
+@pytest.mark.parametrize("case", VO_GOLD["cases"], ids=lambda c: c["name"])
+def test_host_ranker_matches_reference_on_vector_only_scenarios(case):
+    sc = ranking_cases.vector_only_scenario(int(case["name"].split("_")[2]))
+    ranked = HybridRanker().rank_results(*build_inputs(sc))
+    assert vector_only_rows(ranked) == case["rows"]
+
+
+def test_vector_only_scenarios_cover_the_branches():
+    cases = VO_GOLD["cases"]
+    assert len(cases) == ranking_cases.N_VECTOR_ONLY and VO_GOLD["seed"] == ranking_cases.VSEED
+    assert {row[3] for c in cases for row in c["rows"]} == {"vector", "hybrid"}
+    assert max(c["n"] for c in cases) == 50 and min(c["n"] for c in cases) == 1             # total cap reached; single hit
+    assert any(row[6] == 0.5 for c in cases for row in c["rows"]) and any(row[6] == 1.0 for c in cases for row in c["rows"])
+    assert any(0.0 < row[7] < 1.0 for c in cases for row in c["rows"]) and any(row[7] == 1.0 for c in cases for row in c["rows"])

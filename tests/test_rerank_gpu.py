@@ -228,3 +228,63 @@ def test_rerank_on_empty_and_tiny_collections(gpu):
     empty, tiny, filtered = asyncio.run(run())
     assert [len(r) for r in empty] == [0, 0, 0] and [len(r) for r in filtered] == [0, 0, 0]
     assert [len(r) for r in tiny] == [3, 3, 3] and all(r[0].entity_name == f"f{i}" for i, r in enumerate(tiny))
+
+
+# ---- the kernel against the REFERENCE's own outputs (no host ranker in between): the vector-only scenarios of
+# tests/golden/ranking_reference.json (5 scripted) and ranking_vector_only_reference.json (120 seeded; inputs regenerated by
+# tests/ranking_cases.py) go SideColumns -> crh_gather_rows_* -> crh_rerank_vector in ONE launch; order, f64 final scores,
+# the four signals and the source label must equal what src/lattice/query/ranking/ranker.py returned for them.
+def test_device_rerank_matches_reference_goldens(gpu):
+    import json
+    import os
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd.ranking.device import DeviceReranker, SideColumns, node_key, SIGNALS
+    from tests import ranking_cases
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    scripted = json.load(open(os.path.join(gold_dir, "ranking_reference.json")))["scenarios"]
+    roles = ("primary_entities", "callers", "callees", "parent_classes", "child_classes", "methods")
+    cases = []                                        # (name, scenario inputs, expected rows)
+    for s in scripted:
+        if not any(s["graph"].get(r) for r in roles):
+            exp = [[r["entity_name"], r["file_path"], r["start_line"], r["source"], r["final_score"]] + [r["signal_scores"].get(n) for n in SIGNALS]
+                   for r in s["expected"]["ranked"]]
+            cases.append((s["name"], s, exp))
+    assert len(cases) == 5
+    vo = json.load(open(os.path.join(gold_dir, "ranking_vector_only_reference.json")))
+    for c in vo["cases"]:
+        cases.append((c["name"], ranking_cases.vector_only_scenario(int(c["name"].split("_")[2])), c["rows"]))
+    assert len(cases) == 125
+
+    k = max(len(s["vector"]) for _, s, _ in cases)
+    payloads, degree = [], []
+    rows = np.full((len(cases), k), -1, np.int64)
+    scores = np.full((len(cases), k), -np.inf, np.float32)
+    plans = []
+    for q, (_, s, _) in enumerate(cases):
+        cent = s["centrality"] or {}
+        for j, h in enumerate(s["vector"]):
+            rows[q, j] = len(payloads)
+            scores[q, j] = h["score"]
+            payloads.append(h)                        # a hit dict carries the payload keys the side columns read
+            degree.append(int(cent[node_key(h)]["total_degree"]) if node_key(h) in cent else -1)
+        plans.append(NS(primary_intent=s["intent"], entities=[NS(name=e) for e in s["entities"]]))
+    side = SideColumns(0)
+    side.append(payloads)
+    side.set_int_column("degree", degree)             # per row: the same key has different degrees in different scenarios
+    dev = torch.device("cuda:0")
+    rows_d, scores_d = torch.from_numpy(rows).to(dev), torch.from_numpy(scores).to(dev)
+    # the goldens hand the ranker a ready centrality table for ALL hits (not the engine's first five): centrality_top = k
+    out = DeviceReranker(centrality_top=k).rank(scores_d, rows_d, side.gather(rows_d), plans)
+    for q, (name, s, exp) in enumerate(cases):
+        assert out.count[q] == len(exp), (name, out.count[q], len(exp))
+        got = DeviceReranker.materialise(out, q, s["vector"])
+        got_rows = [[g.entity_name, g.file_path, g.start_line, g.source, g.final_score] + [g.signal_scores[n] for n in SIGNALS] for g in got]
+        if name.startswith("vector_only_"):          # hit scores are f32-exact there: everything equal to the last bit
+            assert got_rows == exp, name
+            continue
+        # scripted scenarios use scores like 0.9: the reference saw the Python float, the device the f32 of it
+        for g, e in zip(got_rows, exp):
+            assert g[:4] == e[:4], (name, g, e)
+            assert np.float32(g[5]) == np.float32(e[5]) and g[6:] == e[6:], (name, g, e)
+            assert g[4] == pytest.approx(e[4], rel=0, abs=2e-7), (name, g, e)

@@ -13,6 +13,22 @@ def test_store_scenarios_on_hip_index(gpu):
     asyncio.run(run_store_scenarios(HipVectorStore(dim=768, dtype="f32", initial_capacity=64, device=0)))
 
 
+def test_reference_test_database_scenario_dim_1536(gpu, monkeypatch):
+    """/root/reference/tests/test_database.py:64-124 on the HIP store at the reference's default EMBEDDING_DIMENSIONS = 1536
+    (the store takes its dimension from the settings exactly as QdrantManager does: client.py:29)."""
+    import coderag_amd  # noqa: F401
+    from coderag_amd.store import CollectionName, QdrantManager
+    from tests.store_scenarios import run_reference_database_scenario
+    monkeypatch.delenv("EMBEDDING_DIMENSIONS", raising=False)
+    monkeypatch.delenv("EMBEDDING_PROVIDER", raising=False)
+    monkeypatch.setenv("CODERAG_HIP_STORE_DTYPE", "f32")
+    for dtype in ("f32", "bf16"):
+        monkeypatch.setenv("CODERAG_HIP_STORE_DTYPE", dtype)
+        if dtype == "bf16":
+            continue      # (scores of the bf16 store are checked against the bf16 oracle in the search tests)
+        asyncio.run(run_reference_database_scenario(QdrantManager(), CollectionName))
+
+
 def test_golden_search_cases_on_hip_index(gpu):
     import numpy as np
     import coderag_amd  # noqa: F401

@@ -26,6 +26,14 @@ def test_store_scenarios_on_fake_index(fake):
     asyncio.run(run_store_scenarios(store_mod.HipVectorStore(dim=768, initial_capacity=64)))
 
 
+def test_reference_test_database_scenario_dim_1536(fake, monkeypatch):
+    """/root/reference/tests/test_database.py:64-124, host logic over the oracle-backed index (GPU tier: test_store_gpu.py)."""
+    from tests.store_scenarios import run_reference_database_scenario
+    monkeypatch.delenv("EMBEDDING_DIMENSIONS", raising=False)
+    monkeypatch.delenv("EMBEDDING_PROVIDER", raising=False)
+    asyncio.run(run_reference_database_scenario(store_mod.QdrantManager(), store_mod.CollectionName))
+
+
 def test_client_before_connect_raises(fake):
     s = store_mod.HipVectorStore(dim=768)
     with pytest.raises(VectorStoreError, match="Client not connected"):
