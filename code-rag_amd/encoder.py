@@ -47,16 +47,24 @@ class EncoderConfig:
                    layer_norm_eps=c.get("layer_norm_eps", 1e-5), pad_token_id=c.get("pad_token_id", 1))
 
 
-def synthetic_weights(cfg: EncoderConfig, seed: int) -> dict[str, np.ndarray]:
+def synthetic_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dict[str, np.ndarray]:
     """Seeded stand-in weights under HF ``RobertaModel`` state-dict names (no checkpoint exists offline).  The numpy
-    Generator stream is machine-independent, so every box regenerates the same tensors."""
+    Generator stream is machine-independent, so every box regenerates the same tensors.  ``init="hf"``: the statistics of
+    HF's ``_init_weights`` (N(0, 0.02^2) matrices and tables, zero biases, unit LayerNorm) instead of the sharp O(1) ones."""
     rng = np.random.default_rng(seed)
     H, F = cfg.hidden_size, cfg.intermediate_size
 
+    hf = init == "hf"
+    if init not in ("sharp", "hf"):
+        raise ValueError(f"unknown init {init!r}")
+
     def mat(n, k, std):
+        std = 0.02 if hf else std
         return rng.standard_normal((n, k), dtype=np.float32) * np.float32(std)
 
     def vec(n, std, mean=0.0):
+        if hf:   # (the draw is still made, so both flavours consume the generator identically)
+            return rng.standard_normal(n, dtype=np.float32) * np.float32(0.0) + np.float32(mean)
         return rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean)
     w = {
         "embeddings.word_embeddings.weight": mat(cfg.vocab_size, H, 0.5),

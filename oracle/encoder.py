@@ -38,17 +38,26 @@ class EncoderConfig:
     pad_token_id: int = 1
 
 
-def random_weights(cfg: EncoderConfig, seed: int) -> dict[str, np.ndarray]:
+def random_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dict[str, np.ndarray]:
     """Seeded weights under HF ``RobertaModel`` state-dict names.  numpy's Generator stream is identical on every
     machine, so the GPU box regenerates these bit-for-bit.  Scales are chosen so activations stay O(1) through
-    12 post-LN layers (std 0.02 like HF init would make attention nearly uniform and hide softmax bugs)."""
+    12 post-LN layers (std 0.02 like HF init would make attention nearly uniform and hide softmax bugs).
+    ``init="hf"`` gives the statistics of HF's ``_init_weights`` instead (matrices and tables N(0, 0.02^2), biases 0, LayerNorm
+    weight 1 / bias 0): the second fixture, on which the bf16 pipeline's deviation is reported beside the sharp one."""
     rng = np.random.default_rng(seed)
     H, F = cfg.hidden_size, cfg.intermediate_size
 
+    hf = init == "hf"
+    if init not in ("sharp", "hf"):
+        raise ValueError(f"unknown init {init!r}")
+
     def mat(n, k, std):
+        std = 0.02 if hf else std
         return (rng.standard_normal((n, k), dtype=np.float32) * np.float32(std))
 
     def vec(n, std, mean=0.0):
+        if hf:   # (the draw is still made, so both flavours consume the generator identically)
+            return rng.standard_normal(n, dtype=np.float32) * np.float32(0.0) + np.float32(mean)
         return (rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean))
     w = {
         "embeddings.word_embeddings.weight": mat(cfg.vocab_size, H, 0.5),

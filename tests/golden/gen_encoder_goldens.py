@@ -4,7 +4,7 @@
 Survey-container-only (needs `transformers`; never imported by the package or the tests).  The HF model is built
 locally from a RobertaConfig (no hub access) with is_decoder=False and a 2-D attention mask -- the semantics the
 reference's 3-D mask had under transformers 4.x -- and loaded with the seeded weights of
-oracle.encoder.random_weights.  Writes tests/golden/encoder_{tiny,base}.npz: config, seed, ids and the expected
+oracle.encoder.random_weights.  Writes tests/golden/encoder_{tiny,base,hfinit}.npz: config, seed, ids and the expected
 sentence embeddings (HF fp32).  Weights are NOT stored: they are regenerated from the seed.
 """
 import os
@@ -37,8 +37,8 @@ def hf_forward(cfg: enc.EncoderConfig, weights, ids):
     return sent.numpy(), tok.numpy()
 
 
-def case(name, cfg, seed, lengths, pad_to):
-    w = enc.random_weights(cfg, seed)
+def case(name, cfg, seed, lengths, pad_to, init="sharp"):
+    w = enc.random_weights(cfg, seed, init=init)
     ids = enc.synthetic_ids(cfg, lengths, seed + 1, pad_to=pad_to)
     if name == "tiny":
         ids[1, 5] = cfg.pad_token_id          # an interior pad token: masked as key and in the pool, like the reference's ids.ne(pad)
@@ -52,7 +52,7 @@ def case(name, cfg, seed, lengths, pad_to):
     # pad invariance (quirk Q1): the single-text result equals the padded-batch row
     solo = enc.forward(w, cfg, ids[:1, : lengths[0]])
     assert np.abs(solo[0] - os_[0]).max() < 2e-5
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"encoder_{name}.npz"), seed=seed, ids=ids, sent=hs,
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"encoder_{name}.npz"), seed=seed, ids=ids, sent=hs, init=init,
                         cfg=np.array([cfg.vocab_size, cfg.hidden_size, cfg.num_layers, cfg.num_heads, cfg.intermediate_size,
                                       cfg.max_position_embeddings, cfg.type_vocab_size, cfg.pad_token_id]),
                         eps=cfg.layer_norm_eps)
@@ -63,3 +63,6 @@ if __name__ == "__main__":
     tiny = enc.EncoderConfig(vocab_size=1000, num_layers=2)
     case("tiny", tiny, 11, [17, 64, 9, 40], 64)
     case("base", enc.EncoderConfig(), 23, [128, 33, 77], 128)
+    # the same geometry with HF-init-like statistics (N(0, 0.02^2) matrices, zero biases, unit LayerNorm): real checkpoints sit
+    # between this and the deliberately sharp "base" weights
+    case("hfinit", enc.EncoderConfig(), 29, [128, 33, 77, 200], 208, init="hf")

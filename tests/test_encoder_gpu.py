@@ -218,23 +218,31 @@ def test_embed_ln_and_pool(gpu):
     _close(torch, sent, ref_s, rel=1e-5, abs_=1e-5)          # f32 sums of the same bf16 values, order differs
 
 
-@pytest.mark.parametrize("name", ["tiny", "base"])
+# per fixture: (min cosine, max relative L2) vs the bf16-storage oracle, and vs the fp32 HF fixture
+ENCODER_TOL = {"tiny": ((0.9999, 1e-2), (0.9995, 3e-2)),
+               "base": ((0.9993, 4e-2), (0.997, 8e-2)),
+               "hfinit": ((0.99995, 1e-2), (0.9999, 1.5e-2))}
+
+
+@pytest.mark.parametrize("name", ["tiny", "base", "hfinit"])
 def test_full_encoder_against_hf_fixture(gpu, name):
     """Whole forward against (a) the oracle in its ``bf16_storage`` mode -- f32 arithmetic, bf16 rounding exactly where the
-    kernels store bf16: cosine >= 0.9993, relative L2 <= 4e-2 per sentence (measured: 0.99957 / 2.9e-2 at 12 layers, 0.99999 / 3e-3 at 2) (what is left is accumulation order and
-    exp2/erf implementations acting on a deliberately sharp softmax) -- and (b) the fp32 HF fixture: cosine >= 0.997,
-    relative L2 <= 8e-2.  (b) is the price of bf16 storage itself, not of these kernels: the oracle in bf16_storage mode
-    sits 4.1-5.9e-2 from HF on these seeded weights (weights alone: 3.2e-2), whose 2/sqrt(H) Q/K scale is chosen to make
-    attention non-uniform."""
+    kernels store bf16 -- and (b) the fp32 HF fixture; tolerances per fixture in ENCODER_TOL.
+    ``base`` carries deliberately SHARP weights (O(1) activations, 2/sqrt(H) Q/K scale: attention far from uniform, every
+    rounding amplified through 12 layers): bf16 WEIGHTS ALONE put the f32-arithmetic oracle 3.2e-2 / cosine 0.9995 from HF
+    there, and bf16 activations 5.2-5.9e-2 (tests/test_precision_budget.py pins that budget on CPU), so (b) cannot go below
+    that without f32 weights.  ``hfinit`` is the same geometry with HF-init statistics (N(0, 0.02^2) matrices, unit
+    LayerNorm): the whole bf16 pipeline stays within ~5e-3 of HF there; real checkpoints sit between the two."""
     torch, ffi, dev = _env()
     from coderag_amd import encoder as drv
     from oracle import encoder as orc
     z = np.load(os.path.join(GOLD, f"encoder_{name}.npz"))
+    init = str(z["init"]) if "init" in z.files else "sharp"
     c = [int(v) for v in z["cfg"]]
     kw = dict(vocab_size=c[0], hidden_size=c[1], num_layers=c[2], num_heads=c[3], intermediate_size=c[4],
               max_position_embeddings=c[5], type_vocab_size=c[6], pad_token_id=c[7], layer_norm_eps=float(z["eps"]))
     cfg = drv.EncoderConfig(**kw)
-    weights = drv.synthetic_weights(cfg, int(z["seed"]))
+    weights = drv.synthetic_weights(cfg, int(z["seed"]), init=init)
     model = drv.HipUniXcoder(weights, cfg, drv.HashTokenizer(cfg.vocab_size), 0)
     ids = torch.from_numpy(z["ids"].astype(np.int32)).to(dev)
     got = model.forward_ids(ids).cpu().numpy()
@@ -244,9 +252,13 @@ def test_full_encoder_against_hf_fixture(gpu, name):
         return cos.min(), (np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
     cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True))
     cos_b, rel_b = dist(z["sent"])
-    print(f"encoder[{name}] vs bf16-storage oracle: cos {cos_a:.5f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.5f} rel {rel_b:.4f}")
-    assert cos_a >= 0.9993 and rel_a <= 4e-2, (cos_a, rel_a)
-    assert cos_b >= 0.997 and rel_b <= 8e-2, (cos_b, rel_b)
+    print(f"encoder[{name}] vs bf16-storage oracle: cos {cos_a:.6f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.6f} rel {rel_b:.4f}")
+    os.makedirs(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "encoder_deviation.txt"), "a") as f:
+        f.write(f"{name}: vs bf16-storage oracle cos {cos_a:.6f} rel {rel_a:.5f}; vs HF fp32 cos {cos_b:.6f} rel {rel_b:.5f}\n")
+    (ca, ra), (cb, rb_) = ENCODER_TOL[name]
+    assert cos_a >= ca and rel_a <= ra, (cos_a, rel_a)
+    assert cos_b >= cb and rel_b <= rb_, (cos_b, rel_b)
     # quirk Q1: ragged id lists through the length-bucketing driver give the same vectors as the padded batch
     lists = [row[: int((row != cfg.pad_token_id).sum())].tolist() for row in z["ids"] if cfg.pad_token_id not in row[: int((row != cfg.pad_token_id).sum())]]
     keep = [i for i, row in enumerate(z["ids"]) if cfg.pad_token_id not in row[: int((row != cfg.pad_token_id).sum())]]
