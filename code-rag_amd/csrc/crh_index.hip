@@ -104,7 +104,8 @@ float margin_for(const crh_index *h)
     // bound on |MFMA bf16 score - canonical score| for unit vectors, times 2 ("margin"):
     //  bf16 store: both sums run over the same exact products; f32 accumulation error <= 768*2^-24 each
     //  f32 store : + rounding q and x to bf16 for the scan, <= 2*2^-9 + 2^-18 by Cauchy-Schwarz
-    const float acc = 1.5e-4f;
+    //  (wider rows sum more terms: the bound scales with dim; 1.5e-4 = 1.6 x (2 * 768 * 2^-24) is kept up to dim 768)
+    const float acc = 1.5e-4f * (h->dim > 768 ? (float)h->dim / 768.f : 1.f);
     return h->dtype == CRH_DTYPE_BF16 ? 2.f * acc : 2.f * (acc + 3.92e-3f);
 }
 
@@ -504,6 +505,89 @@ int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows)
     return CRH_OK;
 }
 
+int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_filters, int64_t *n_cleared_out)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (n_cleared_out) *n_cleared_out = 0;
+    if (n_filters <= 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 1..%d (a delete needs a filter)", n_filters, CRH_MAX_FILTERS);
+    if (!filters) return fail(CRH_E_INVALID, "filters is NULL");
+    if (h->count == 0) return CRH_OK;
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());   // searches in flight on other streams read `alive` / the shared mask buffer
+    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    const uint32_t *mask = nullptr;
+    CRH_TRY(build_mask(h, filters, n_filters, &mask, nullptr));
+    const int64_t ntiles = ceil_div(h->count, 32);
+    CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
+    hipLaunchKernelGGL(k_tombstone_mask, dim3((unsigned)ceil_div(ntiles, 256)), dim3(256), 0, 0, h->alive, mask, ntiles, h->scratch_u32);
+    CRH_HIP(hipGetLastError());
+    unsigned int cleared = 0;
+    CRH_HIP(hipMemcpy(&cleared, h->scratch_u32, 4, hipMemcpyDeviceToHost));
+    h->alive_count -= cleared;
+    if (n_cleared_out) *n_cleared_out = cleared;
+    return CRH_OK;
+}
+
+int crh_index_export(crh_index *h, int64_t first_tile, int64_t n_tiles, void *tiles_host, float *master_host, uint32_t *alive_host,
+                     int32_t *codes_host)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    const int64_t used_tiles = ceil_div(h->count, 32);
+    if (first_tile < 0 || n_tiles < 0 || first_tile + n_tiles > used_tiles)
+        return fail(CRH_E_INVALID, "tile range [%lld,+%lld) outside the %lld tiles in use", (long long)first_tile, (long long)n_tiles, (long long)used_tiles);
+    if (n_tiles == 0) return CRH_OK;
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());
+    const size_t tile_bytes = (size_t)h->ksteps * 1024;
+    if (tiles_host) CRH_HIP(hipMemcpy(tiles_host, reinterpret_cast<const char *>(h->xt) + (size_t)first_tile * tile_bytes, (size_t)n_tiles * tile_bytes, hipMemcpyDeviceToHost));
+    const int64_t r0 = first_tile * 32, nr = std::min(n_tiles * 32, h->cap_rows - r0);
+    if (master_host) {
+        if (!h->xf32) return fail(CRH_E_INVALID, "export: this index keeps no f32 master copy (dtype bf16)");
+        CRH_HIP(hipMemcpy(master_host, h->xf32 + r0 * h->dim, (size_t)nr * h->dim * 4, hipMemcpyDeviceToHost));
+        if (r0 + nr > h->count)   // slots of the last tile past the row count were never written: the file gets zeros there
+            memset(master_host + (h->count - r0) * h->dim, 0, (size_t)(r0 + nr - h->count) * h->dim * 4);
+    }
+    if (alive_host) CRH_HIP(hipMemcpy(alive_host, h->alive + first_tile, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    if (codes_host)
+        for (int c = 0; c < h->ncols; ++c)
+            CRH_HIP(hipMemcpy(codes_host + (int64_t)c * n_tiles * 32, h->codes + (int64_t)c * h->cap_rows + r0, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    return CRH_OK;
+}
+
+int crh_index_import(crh_index *h, int64_t first_tile, int64_t n_tiles, int64_t rows_after, const void *tiles_host,
+                     const float *master_host, const uint32_t *alive_host, const int32_t *codes_host)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (first_tile < 0 || n_tiles <= 0 || first_tile + n_tiles > h->cap_tiles)
+        return fail(CRH_E_CAPACITY, "import of tiles [%lld,+%lld) exceeds the capacity of %lld tiles (reserve first)", (long long)first_tile,
+                    (long long)n_tiles, (long long)h->cap_tiles);
+    if (first_tile * 32 != ((h->count + 31) & ~31LL))
+        return fail(CRH_E_INVALID, "import must continue at the end of the index (tile %lld, got %lld)", (long long)(((h->count + 31) & ~31LL) / 32), (long long)first_tile);
+    if (rows_after <= first_tile * 32 || rows_after > (first_tile + n_tiles) * 32 || rows_after <= (first_tile + n_tiles - 1) * 32)
+        return fail(CRH_E_INVALID, "rows_after=%lld does not end inside the last imported tile", (long long)rows_after);
+    if (!tiles_host || !alive_host) return fail(CRH_E_INVALID, "import: tiles and alive words are required");
+    if ((h->xf32 != nullptr) != (master_host != nullptr)) return fail(CRH_E_INVALID, "import: the f32 master copy goes with dtype f32, and only with it");
+    if ((h->ncols > 0) != (codes_host != nullptr)) return fail(CRH_E_INVALID, "import: index has %d code columns", h->ncols);
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());
+    const size_t tile_bytes = (size_t)h->ksteps * 1024;
+    const int64_t r0 = first_tile * 32, nr = n_tiles * 32;
+    CRH_HIP(hipMemcpy(reinterpret_cast<char *>(h->xt) + (size_t)first_tile * tile_bytes, tiles_host, (size_t)n_tiles * tile_bytes, hipMemcpyHostToDevice));
+    if (master_host) CRH_HIP(hipMemcpy(h->xf32 + r0 * h->dim, master_host, (size_t)nr * h->dim * 4, hipMemcpyHostToDevice));
+    // rows past rows_after in the last tile are not rows of the index: their alive bits must stay clear
+    std::vector<uint32_t> al(alive_host, alive_host + n_tiles);
+    const int tail = (int)(rows_after - (first_tile + n_tiles - 1) * 32);
+    if (tail < 32) al[(size_t)n_tiles - 1] &= (1u << tail) - 1u;
+    int64_t alive_rows = 0;
+    for (uint32_t w : al) alive_rows += __builtin_popcount(w);
+    CRH_HIP(hipMemcpy(h->alive + first_tile, al.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice));
+    for (int c = 0; c < h->ncols; ++c)
+        CRH_HIP(hipMemcpy(h->codes + (int64_t)c * h->cap_rows + r0, codes_host + (int64_t)c * nr, (size_t)nr * 4, hipMemcpyHostToDevice));
+    h->count = rows_after;
+    h->alive_count += alive_rows;
+    return CRH_OK;
+}
+
 int crh_index_count(crh_index *h, int64_t *rows_out, int64_t *alive_out)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
@@ -771,8 +855,7 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
 {
     if (!h || !n_out) return fail(CRH_E_INVALID, "NULL argument");
     *n_out = 0;
-    if (limit <= 0 || h->count == 0) return CRH_OK;
-    if (!rows_out_host) return fail(CRH_E_INVALID, "rows_out_host is NULL");
+    if (limit <= 0 || h->count == 0) return CRH_OK;   // (rows_out_host == NULL: count only, up to `limit`)
     if (n_filters < 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 0..%d", n_filters, CRH_MAX_FILTERS);
     DeviceGuard g(h->device);
     CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
@@ -787,7 +870,8 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
         while (m && found < limit) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
-            rows_out_host[found++] = t * 32 + b;
+            if (rows_out_host) rows_out_host[found] = t * 32 + b;
+            ++found;
         }
     }
     *n_out = found;

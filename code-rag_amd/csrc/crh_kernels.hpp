@@ -202,6 +202,19 @@ __global__ __launch_bounds__(256) void k_filter_mask(const uint32_t *__restrict_
     }
 }
 
+// delete-by-filter: clear every alive bit the (already alive-ANDed) filter mask has set; counts the cleared rows
+__global__ void k_tombstone_mask(uint32_t *__restrict__ alive, const uint32_t *__restrict__ mask, int64_t ntiles,
+                                 unsigned int *cleared)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t m = mask[t] & alive[t];
+    if (m) {
+        alive[t] &= ~m;
+        atomicAdd(cleared, (unsigned int)__popc(m));
+    }
+}
+
 // untile rows [first, first+n) into f32 [n][dim] (the bf16 copy; exact bf16 values)
 __global__ void k_untile_rows(const u32x4 *__restrict__ xt, int ksteps, int64_t first, int64_t n, int dim,
                               float *__restrict__ out)

@@ -23,6 +23,7 @@ MAX_FILTERS, MAX_K = 8, 1024
 EXPORTS = (
     "crh_abi_version", "crh_last_error", "crh_device_count", "crh_device_info",
     "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_append_preprocessed", "crh_index_tombstone",
+    "crh_index_tombstone_filter", "crh_index_export", "crh_index_import",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
@@ -121,6 +122,9 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_index_append.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
     L.crh_index_append_preprocessed.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
     L.crh_index_tombstone.argtypes = [vp, i64, vp]
+    L.crh_index_tombstone_filter.argtypes = [vp, C.POINTER(Filter), i32, C.POINTER(i64)]
+    L.crh_index_export.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    L.crh_index_import.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
     L.crh_index_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.crh_index_clear.argtypes = [vp]
     L.crh_index_reserve.argtypes = [vp, i64]
@@ -289,6 +293,106 @@ class Index:
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         check(lib().crh_index_tombstone(self._handle(), rows.shape[0], rows.ctypes.data))
 
+    def tombstone_filter(self, filters) -> int:
+        """Delete every alive row matching all ``(column, code)`` predicates, on the device; returns how many."""
+        farr, nf = _filters(filters)
+        n = C.c_int64(0)
+        check(lib().crh_index_tombstone_filter(self._handle(), farr, nf, C.byref(n)))
+        return int(n.value)
+
+    # ------------------------------------------------------------------ snapshot (SURVEY.md section 8f, row 2)
+    SNAPSHOT_FORMAT = 2
+    SNAPSHOT_CHUNK_TILES = 1 << 15          # 32768 tiles = 1M rows per transfer (1.5 GiB of tiles at dim 768)
+
+    def save(self, directory: str) -> dict:
+        """Write the stored image VERBATIM into ``directory``: ``tiles.bin`` (the tiled bf16 image, raw and mmap-able:
+        rows/32 tiles of dim/16 KiB), ``master.f32`` ([rows padded to 32, dim] f32; f32 store only), ``alive.u32`` (one word
+        per tile, tombstones included), ``codes.i32`` ([n_code_cols][rows padded to 32] int32, columnar) and ``index.json``.
+        No pickle, no compression, no f32 inflation of a bf16 store: 10M x 768 bf16 is 15.36 GB on disk."""
+        import json
+        rows, alive = self.count()
+        ntiles = (rows + 31) // 32
+        tile_bytes = self.dim // 16 * 1024
+        os.makedirs(directory, exist_ok=True)
+        meta = {"format": self.SNAPSHOT_FORMAT, "dim": self.dim, "dtype": "bf16" if self.dtype == DTYPE_BF16 else "f32",
+                "rows": rows, "alive": alive, "tiles": ntiles, "n_code_cols": self.n_code_cols, "tile_bytes": tile_bytes,
+                "files": {"tiles": "tiles.bin", "alive": "alive.u32", "codes": "codes.i32" if self.n_code_cols else None,
+                          "master": "master.f32" if self.dtype == DTYPE_F32 else None}}
+
+        def mm(name, dtype, shape):
+            if 0 in shape:
+                open(os.path.join(directory, name), "wb").close()
+                return None
+            return np.memmap(os.path.join(directory, name), dtype=dtype, mode="w+", shape=shape)
+        tiles = mm("tiles.bin", np.uint8, (ntiles, tile_bytes))
+        al = mm("alive.u32", np.uint32, (ntiles,))
+        master = mm("master.f32", np.float32, (ntiles * 32, self.dim)) if self.dtype == DTYPE_F32 else None
+        codes = mm("codes.i32", np.int32, (self.n_code_cols, ntiles * 32)) if self.n_code_cols else None
+        for t0 in range(0, ntiles, self.SNAPSHOT_CHUNK_TILES):
+            nt = min(self.SNAPSHOT_CHUNK_TILES, ntiles - t0)
+            cbuf = np.empty((self.n_code_cols, nt * 32), np.int32) if self.n_code_cols else None
+            check(lib().crh_index_export(self._handle(), t0, nt, tiles[t0:t0 + nt].ctypes.data,
+                                         master[t0 * 32:(t0 + nt) * 32].ctypes.data if master is not None else None,
+                                         al[t0:t0 + nt].ctypes.data, cbuf.ctypes.data if cbuf is not None else None))
+            if cbuf is not None:
+                codes[:, t0 * 32:(t0 + nt) * 32] = cbuf
+        for m in (tiles, al, master, codes):
+            if m is not None:
+                m.flush()
+        del tiles, al, master, codes
+        with open(os.path.join(directory, "index.json"), "w") as f:
+            json.dump(meta, f)
+        return meta
+
+    def load(self, directory: str) -> dict:
+        """Fill this EMPTY index from a directory written by :meth:`save` (same dim / dtype / code columns): the files are
+        memory-mapped and moved to HBM chunk by chunk; searches answer with the same ids and identical score bits."""
+        import json
+        with open(os.path.join(directory, "index.json")) as f:
+            meta = json.load(f)
+        want = {"format": self.SNAPSHOT_FORMAT, "dim": self.dim, "dtype": "bf16" if self.dtype == DTYPE_BF16 else "f32",
+                "n_code_cols": self.n_code_cols}
+        for key, val in want.items():
+            if meta.get(key) != val:
+                raise NativeError(E_INVALID, f"snapshot {directory} has {key}={meta.get(key)!r}, this index {val!r}")
+        if self.count()[0] != 0:
+            raise NativeError(E_INVALID, "load() needs an empty index")
+        rows, ntiles, tile_bytes = int(meta["rows"]), int(meta["tiles"]), int(meta["tile_bytes"])
+        if ntiles != (rows + 31) // 32 or tile_bytes != self.dim // 16 * 1024:
+            raise NativeError(E_INVALID, f"snapshot {directory}: inconsistent index.json")
+        if rows == 0:
+            return meta
+        self.reserve(rows)
+
+        def mm(name, dtype, shape):
+            path = os.path.join(directory, name)
+            if os.path.getsize(path) != int(np.prod(shape)) * np.dtype(dtype).itemsize:
+                raise NativeError(E_INVALID, f"snapshot file {path} has the wrong size")
+            return np.memmap(path, dtype=dtype, mode="r", shape=shape)
+        tiles = mm("tiles.bin", np.uint8, (ntiles, tile_bytes))
+        al = mm("alive.u32", np.uint32, (ntiles,))
+        master = mm("master.f32", np.float32, (ntiles * 32, self.dim)) if self.dtype == DTYPE_F32 else None
+        codes = mm("codes.i32", np.int32, (self.n_code_cols, ntiles * 32)) if self.n_code_cols else None
+        for t0 in range(0, ntiles, self.SNAPSHOT_CHUNK_TILES):
+            nt = min(self.SNAPSHOT_CHUNK_TILES, ntiles - t0)
+            cbuf = np.ascontiguousarray(codes[:, t0 * 32:(t0 + nt) * 32]) if codes is not None else None
+            abuf = np.ascontiguousarray(al[t0:t0 + nt])
+            check(lib().crh_index_import(self._handle(), t0, nt, min(rows, (t0 + nt) * 32), tiles[t0:t0 + nt].ctypes.data,
+                                         master[t0 * 32:(t0 + nt) * 32].ctypes.data if master is not None else None,
+                                         abuf.ctypes.data, cbuf.ctypes.data if cbuf is not None else None))
+        got_rows, got_alive = self.count()
+        if got_rows != rows or got_alive != int(meta["alive"]):
+            raise NativeError(E_INTERNAL, f"snapshot {directory}: restored {got_rows} rows / {got_alive} alive, index.json says {rows} / {meta['alive']}")
+        return meta
+
+    def alive_words(self) -> np.ndarray:
+        """One validity word per 32-row tile (bit b of word t = row 32t+b is alive)."""
+        ntiles = (self.count()[0] + 31) // 32
+        out = np.zeros((ntiles,), np.uint32)
+        if ntiles:
+            check(lib().crh_index_export(self._handle(), 0, ntiles, None, None, out.ctypes.data, None))
+        return out
+
     def count(self) -> tuple[int, int]:
         r, a = C.c_int64(0), C.c_int64(0)
         check(lib().crh_index_count(self._handle(), C.byref(r), C.byref(a)))
@@ -347,6 +451,13 @@ class Index:
         ms, n = C.c_double(0.0), C.c_int64(0)
         check(lib().crh_index_get_profile(self._handle(), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def count_matching(self, filters=None) -> int:
+        """Number of alive rows matching the filters (resolved on the device)."""
+        farr, nf = _filters(filters)
+        n = C.c_int64(0)
+        check(lib().crh_index_match_rows(self._handle(), farr, nf, 1 << 62, None, C.byref(n)))
+        return int(n.value)
 
     def match_rows(self, filters=None, limit: int = 1) -> np.ndarray:
         farr, nf = _filters(filters)

@@ -44,7 +44,9 @@ def merge_key(payload: dict[str, Any]) -> str:
 
 
 class SideColumns:
-    """Per-row side data of one collection shard, resident on the device; rows are appended in store order."""
+    """Per-row side data of one collection shard, resident on the device; rows are appended in store order.  Host and device
+    copies grow geometrically and an append uploads ONLY the new rows (a re-rank after every upsert does not re-send the
+    collection); replacing a whole column (graph degrees) re-sends that column alone."""
 
     INT_COLS = ("content_len", "degree", "file_code", "key_code", "node_code", "name_len")
 
@@ -53,65 +55,97 @@ class SideColumns:
         self._torch = torch
         self.device = torch.device("cuda", device)
         self.rows = 0
-        self._host: dict[str, list] = {c: [] for c in self.INT_COLS}
-        self._names: list[bytes] = []
+        self._host: dict[str, np.ndarray] = {c: np.zeros((0,), np.int32) for c in self.INT_COLS}
+        self._names = np.zeros((0, ffi.RR_NAME_BYTES), np.uint8)
         self._books: dict[str, dict[str, int]] = {"file": {}, "key": {}, "node": {}}
         self._node_keys: list[str] = []
-        self._dev: dict[str, Any] | None = None
+        self._dev: dict[str, Any] | None = None      # device tensors with capacity >= rows
+        self._dev_rows = 0                           # rows already uploaded
+        self._dirty: set[str] = set()                # columns replaced wholesale since the last upload
 
     def _code(self, book: str, value: str) -> int:
         b = self._books[book]
         return b.setdefault(value, len(b) + 1)
 
+    def _grow_host(self, need: int) -> None:
+        cap = len(self._names)
+        if need <= cap:
+            return
+        cap = max(need, 2 * cap, 1024)
+        for c in self.INT_COLS:
+            new = np.zeros((cap,), np.int32)
+            new[: self.rows] = self._host[c][: self.rows]
+            self._host[c] = new
+        names = np.zeros((cap, ffi.RR_NAME_BYTES), np.uint8)
+        names[: self.rows] = self._names[: self.rows]
+        self._names = names
+
     def append(self, payloads: Sequence[dict[str, Any] | None]) -> None:
         """Rows in store order; ``None`` (a tombstoned row) keeps the numbering aligned."""
-        h = self._host
-        for p in payloads:
+        n = len(payloads)
+        if n == 0:
+            return
+        self._grow_host(self.rows + n)
+        h, r0 = self._host, self.rows
+        width = ffi.RR_NAME_BYTES
+        for j, p in enumerate(payloads):
             p = p or {}
+            r = r0 + j
             content = p.get("content")
             name = (p.get("entity_name", "") or "").lower().encode("utf-8")
-            h["content_len"].append(len(content) if content else 0)
-            h["degree"].append(-1)
-            h["file_code"].append(self._code("file", p.get("file_path", "") or ""))
-            h["key_code"].append(self._code("key", merge_key(p)))
+            h["content_len"][r] = len(content) if content else 0
+            h["degree"][r] = -1
+            h["file_code"][r] = self._code("file", p.get("file_path", "") or "")
+            h["key_code"][r] = self._code("key", merge_key(p))
             nk = node_key(p)
-            h["node_code"].append(self._code("node", nk))
-            h["name_len"].append(len(name))
+            h["node_code"][r] = self._code("node", nk)
+            h["name_len"][r] = len(name)
             self._node_keys.append(nk)
-            self._names.append(name[: ffi.RR_NAME_BYTES].ljust(ffi.RR_NAME_BYTES, b"\0"))
-        self.rows = len(self._names)
-        self._dev = None
+            if name:
+                self._names[r, : min(len(name), width)] = np.frombuffer(name[:width], dtype=np.uint8)
+        self.rows = r0 + n
 
     def set_degrees(self, total_degree: dict[str, int]) -> None:
         """``{centrality key: total_degree}`` as the graph reports it; keys it does not know stay at -1."""
-        self._host["degree"] = [int(total_degree.get(k, -1)) for k in self._node_keys]
-        self._dev = None
+        self._host["degree"][: self.rows] = np.fromiter((int(total_degree.get(k, -1)) for k in self._node_keys), np.int32, self.rows)
+        self._dirty.add("degree")
 
     def set_int_column(self, name: str, values) -> None:
         """Bulk load of one column (synthetic corpora: arrays generated without payload dictionaries)."""
         v = np.asarray(values, dtype=np.int32)
         if v.shape != (self.rows,):
             raise ValueError(f"column {name} needs {self.rows} values")
-        self._host[name] = v
-        self._dev = None
+        self._host[name][: self.rows] = v
+        self._dirty.add(name)
 
     @classmethod
     def from_arrays(cls, device: int, **cols) -> "SideColumns":
         """Columns given as arrays (``name`` as uint8 [rows, 64]); no dictionaries are kept."""
         self = cls(device)
         self.rows = int(len(cols["content_len"]))
-        self._host = {c: np.asarray(cols[c], dtype=np.int32) for c in cls.INT_COLS}
+        self._host = {c: np.ascontiguousarray(cols[c], dtype=np.int32) for c in cls.INT_COLS}
         self._names = np.ascontiguousarray(cols["name"], dtype=np.uint8).reshape(self.rows, ffi.RR_NAME_BYTES)
         return self
 
     def _resident(self) -> dict[str, Any]:
-        if self._dev is None:
-            t = self._torch
-            dev = {c: t.from_numpy(np.asarray(self._host[c], dtype=np.int32)).to(self.device) for c in self.INT_COLS}
-            names = self._names if isinstance(self._names, np.ndarray) else \
-                np.frombuffer(b"".join(self._names), dtype=np.uint8).reshape(self.rows, ffi.RR_NAME_BYTES)
-            dev["name"] = t.from_numpy(np.array(names, dtype=np.uint8)).to(self.device)
-            self._dev = dev
+        t = self._torch
+        if self._dev is None or int(self._dev["name"].shape[0]) < self.rows:         # (re)allocate with headroom, keep what is there
+            cap = max(self.rows, 2 * (int(self._dev["name"].shape[0]) if self._dev else 0), 1024)
+            new = {c: t.zeros((cap,), dtype=t.int32, device=self.device) for c in self.INT_COLS}
+            new["name"] = t.zeros((cap, ffi.RR_NAME_BYTES), dtype=t.uint8, device=self.device)
+            if self._dev is not None and self._dev_rows:
+                for c in new:
+                    new[c][: self._dev_rows].copy_(self._dev[c][: self._dev_rows])
+            self._dev = new
+        lo, hi = self._dev_rows, self.rows
+        if hi > lo:
+            for c in self.INT_COLS:
+                self._dev[c][lo:hi].copy_(t.from_numpy(self._host[c][lo:hi]))
+            self._dev["name"][lo:hi].copy_(t.from_numpy(self._names[lo:hi]))
+            self._dev_rows = hi
+        for c in self._dirty:
+            self._dev[c][: self.rows].copy_(t.from_numpy(self._host[c][: self.rows]))
+        self._dirty.clear()
         return self._dev
 
     def gather(self, rows_dev, row_base: int = 0, stream: int | None = None) -> dict[str, Any]:

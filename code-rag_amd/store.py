@@ -72,7 +72,15 @@ def _hashable(v: Any) -> Any:
 
 
 class _Collection:
-    """One collection: a device index + the host-side id/payload tables."""
+    """One collection: a device index + the host-side id / payload tables.
+
+    What lives where: vectors, validity bits and the dictionary CODES of the filterable payload keys are on the device
+    (columnar int32, one column per key); the host keeps, per row, only the id string and the payload dictionary a hit has
+    to carry back, plus one value<->code dictionary per key.  Filters, deletes and the update check are resolved on the
+    device from the code columns (``crh_index_match_rows`` / ``crh_index_tombstone_filter``): no per-row Python sets, no
+    host copy of the validity bits.  Rows are never reused, so a deleted row's id / payload entries are simply left behind
+    (a stale ``row_of_id`` entry only ever leads to tombstoning a dead row again, which the device ignores) and are dropped
+    when the collection is saved."""
 
     def __init__(self, name: str, dim: int, dtype: int, capacity: int, device: int):
         self.name = name
@@ -82,7 +90,6 @@ class _Collection:
         self.payloads: list[dict | None] = []
         self.row_of_id: dict[str, int] = {}
         self.codebooks: list[dict[Any, int]] = [dict() for _ in self.keys]   # value -> code (>= 1; 0 = missing/None)
-        self.rows_by_code: list[dict[int, set[int]]] = [dict() for _ in self.keys]
         self._side = None          # ranking.device.SideColumns of the rows appended so far (built on first use)
         self._degrees: dict[str, int] | None = None
         self._device = device
@@ -104,15 +111,26 @@ class _Collection:
             self._side.set_degrees(self._degrees)
 
     # -- payload coding
-    def _encode(self, payload: dict) -> list[int]:
-        codes = []
+    def _encode_columns(self, payloads: list[dict]) -> np.ndarray:
+        """[n, n_keys] int32 codes, one key (= one device column) at a time."""
+        codes = np.zeros((len(payloads), len(self.keys)), dtype=np.int32)
         for c, key in enumerate(self.keys):
-            v = payload.get(key)
-            if v is None:
-                codes.append(0)
-                continue
             book = self.codebooks[c]
-            codes.append(book.setdefault(_hashable(v), len(book) + 1))
+            col = []
+            for p in payloads:
+                v = p.get(key)
+                if v is None:
+                    col.append(0)
+                    continue
+                try:
+                    code = book.get(v)
+                except TypeError:           # an unhashable value (list / dict payload field)
+                    v = repr(v)
+                    code = book.get(v)
+                if code is None:
+                    code = book[v] = len(book) + 1
+                col.append(code)
+            codes[:, c] = col
         return codes
 
     def device_filters(self, filters: dict[str, Any] | None) -> list[tuple[int, int]] | None:
@@ -129,84 +147,125 @@ class _Collection:
             out.append((c, code))
         return out
 
-    def host_rows(self, filters: dict[str, Any]) -> list[int]:
-        """Alive rows matching every equality, ascending (inverted-index intersection on the host)."""
-        sets = []
-        for c, code in self.device_filters(filters) or [(-1, -1)]:
-            if c < 0:
-                return []
-            sets.append(self.rows_by_code[c].get(code, set()))
-        if not sets:
-            return [r for r, p in enumerate(self.payloads) if p is not None]
-        sets.sort(key=len)
-        rows = set(sets[0])
-        for s in sets[1:]:
-            rows &= s
-        return sorted(rows)
+    def matching_rows(self, filters: dict[str, Any] | None, limit: int | None = None) -> np.ndarray:
+        """Alive rows matching every equality, ascending -- resolved on the device from the code columns."""
+        dfilt = self.device_filters(filters)
+        if dfilt is None:
+            return np.zeros((0,), np.int64)
+        return self.index.match_rows(dfilt, self.index.count()[0] if limit is None else limit)
 
     # -- mutation
-    def _forget(self, rows: list[int]) -> None:
-        for r in rows:
-            payload, pid = self.payloads[r], self.ids[r]
-            if payload is None:
-                continue
-            for c, code in enumerate(self._encode(payload)):
-                self.rows_by_code[c].get(code, set()).discard(r)
-            self.payloads[r] = None
-            self.ids[r] = None
-            if pid is not None and self.row_of_id.get(pid) == r:
-                del self.row_of_id[pid]
+    def remove_rows(self, rows) -> None:
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size:
+            self.index.tombstone(rows)
 
-    def remove_rows(self, rows: list[int]) -> None:
-        rows = [r for r in rows if self.payloads[r] is not None]
-        if rows:
-            self.index.tombstone(np.asarray(rows, dtype=np.int64))
-            self._forget(rows)
+    def delete(self, filters: dict[str, Any]) -> int:
+        """client.py:159-169: every point matching the AND of equalities.  An empty filter matches every point, as
+        ``Filter(must=[])`` does."""
+        dfilt = self.device_filters(filters)
+        if dfilt is None:
+            return 0
+        if not dfilt:
+            rows = self.index.match_rows(None, self.index.count()[0])
+            self.remove_rows(rows)
+            return int(rows.size)
+        return self.index.tombstone_filter(dfilt)
 
-    def upsert(self, ids: list[str], vectors, payloads: list[dict], preprocessed: bool = False) -> None:
+    def upsert(self, ids, vectors, payloads, preprocessed: bool = False) -> None:
+        """``vectors``: list of float lists (what the reference passes), a float32 ndarray [n, dim], or a CUDA tensor [n, dim]
+        on this collection's device (no host round trip)."""
         n = len(ids)
         if n == 0:
             return
-        vecs = np.asarray(vectors, dtype=np.float32)
-        if vecs.ndim != 2 or vecs.shape[0] != n or len(payloads) != n:
-            raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {vecs.shape}, {len(payloads)})")
-        if vecs.shape[1] != self.index.dim:
+        on_dev = not isinstance(vectors, (list, tuple, np.ndarray)) and bool(getattr(vectors, "is_cuda", False))
+        vecs = vectors if on_dev else np.asarray(vectors, dtype=np.float32)
+        if vecs.ndim != 2 or int(vecs.shape[0]) != n or len(payloads) != n:
+            raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {tuple(vecs.shape)}, {len(payloads)})")
+        if int(vecs.shape[1]) != self.index.dim:
             raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.index.dim}")
-        last = {pid: i for i, pid in enumerate(ids)}           # a repeated id inside one call: last one wins
-        keep = sorted(last.values())
-        stale = [self.row_of_id[pid] for pid in last if pid in self.row_of_id]
-        codes = np.asarray([self._encode(payloads[i]) for i in keep], dtype=np.int32).reshape(len(keep), len(self.keys))
+        ids = [str(i) for i in ids]
+        last = dict(zip(ids, range(n)))                       # a repeated id inside one call: last one wins
+        if len(last) != n:
+            keep = sorted(last.values())
+            ids, payloads = [ids[i] for i in keep], [payloads[i] for i in keep]
+            vecs = vecs[keep] if not on_dev else vecs[ffi_index_tensor(vecs, keep)]
+            n = len(keep)
+        known = self.row_of_id
+        stale = [known[pid] for pid in ids if pid in known]
+        codes = self._encode_columns(payloads)
         rows_now, _ = self.index.count()
-        need = rows_now + len(keep)
+        need = rows_now + n
         if need > self.index.capacity_rows:
             self.index.reserve(max(need, 2 * self.index.capacity_rows))
-        first = self.index.append(vecs[keep], codes if self.keys else None, preprocessed=preprocessed)
-        self.remove_rows(stale)
-        for j, i in enumerate(keep):
-            r = first + j
-            self.ids.append(str(ids[i]))
-            self.payloads.append(dict(payloads[i]))
-            self.row_of_id[str(ids[i])] = r
-            for c, code in enumerate(codes[j]):
-                self.rows_by_code[c].setdefault(int(code), set()).add(r)
-
-    def snapshot(self) -> tuple[list[str], np.ndarray, list[dict]]:
-        """(ids, stored vectors, payloads) of the live points, tombstones compacted away."""
-        rows = [r for r, p in enumerate(self.payloads) if p is not None]
-        total, _ = self.index.count()
-        stored = self.index.read_rows(0, total) if total else np.zeros((0, self.index.dim), np.float32)
-        return [self.ids[r] for r in rows], stored[rows], [self.payloads[r] for r in rows]
+        if on_dev:
+            import torch
+            vecs = vecs.contiguous() if vecs.dtype == torch.float32 else vecs.float().contiguous()
+            cdev = torch.from_numpy(codes).to(vecs.device) if self.keys else None
+            first = self.index.append(vecs, cdev, stream=ffi.current_stream(vecs.device), preprocessed=preprocessed)
+            torch.cuda.current_stream(vecs.device).synchronize()      # the caller may free / reuse its tensor right away
+        else:
+            first = self.index.append(vecs, codes if self.keys else None, preprocessed=preprocessed)
+        if stale:
+            self.remove_rows(stale)
+        self.ids.extend(ids)
+        self.payloads.extend([dict(p) for p in payloads])
+        known.update(zip(ids, range(first, first + n)))
 
     def hit(self, row: int, score: float) -> dict[str, Any]:
         return {"id": self.ids[row], "score": score, "payload": dict(self.payloads[row] or {})}
+
+    # -- persistence (SURVEY.md section 8f, row 2)
+    def save(self, directory: str) -> None:
+        """``directory``: the index image (``ffi.Index.save``: raw, mmap-able, verbatim) + ``ids.jsonl`` / ``payloads.jsonl``
+        (one JSON value per row, ``null`` for a deleted row) + ``collection.json`` (keys, code dictionaries, graph degrees)."""
+        import json
+        self.index.save(directory)
+        words = self.index.alive_words()
+        alive = np.unpackbits(words.view(np.uint8), bitorder="little")[: len(self.ids)].astype(bool) if len(self.ids) else np.zeros(0, bool)
+        dumps = json.dumps
+        with open(os.path.join(directory, "ids.jsonl"), "w") as fi, open(os.path.join(directory, "payloads.jsonl"), "w") as fp:
+            for r, (pid, payload) in enumerate(zip(self.ids, self.payloads)):
+                ok = alive[r]
+                fi.write((dumps(pid) if ok else "null") + "\n")
+                fp.write((dumps(payload) if ok else "null") + "\n")
+        books = [[v for v, _ in sorted(book.items(), key=lambda kv: kv[1])] for book in self.codebooks]
+        with open(os.path.join(directory, "collection.json"), "w") as f:
+            json.dump({"name": self.name, "keys": list(self.keys), "codebooks": books, "degrees": self._degrees}, f, default=repr)
+
+    def load(self, directory: str) -> None:
+        import json
+        with open(os.path.join(directory, "collection.json")) as f:
+            meta = json.load(f)
+        if list(meta["keys"]) != list(self.keys):
+            raise ValueError(f"snapshot of {self.name} codes the payload keys {meta['keys']}, this store {list(self.keys)}")
+        self.index.load(directory)
+        self.codebooks = [{_hashable(v): i + 1 for i, v in enumerate(book)} for book in meta["codebooks"]]
+        with open(os.path.join(directory, "ids.jsonl")) as f:
+            self.ids = [json.loads(line) for line in f]
+        with open(os.path.join(directory, "payloads.jsonl")) as f:
+            self.payloads = [json.loads(line) for line in f]
+        rows, _ = self.index.count()
+        if len(self.ids) != rows or len(self.payloads) != rows:
+            raise ValueError(f"snapshot of {self.name}: {rows} rows in the index, {len(self.ids)} ids, {len(self.payloads)} payloads")
+        self.row_of_id = {pid: r for r, pid in enumerate(self.ids) if pid is not None}
+        self._side = None
+        self._degrees = meta.get("degrees")
 
     def close(self) -> None:
         self.index.close()
 
 
+def ffi_index_tensor(vecs, keep):
+    import torch
+    return torch.as_tensor(keep, device=vecs.device, dtype=torch.int64)
+
+
 class _RawClient:
     """The slice of ``AsyncQdrantClient`` that callers reach through ``QdrantManager.client``
     (health check: client.py:66; admin cleanup: projects/cleanup.py:41-61)."""
+
+    MAX_CODE_COMBINATIONS = 4096
 
     def __init__(self, store: "HipVectorStore"):
         self._store = store
@@ -230,23 +289,49 @@ class _RawClient:
                 out.append((cond.key, "value", getattr(m, "value", None)))
         return out
 
-    def _select(self, collection_name: str, flt) -> list[int]:
-        col = self._store._col(collection_name)
-        conds = self._conditions(flt)
+    def _device_plans(self, col: _Collection, conds) -> list[list[tuple[int, int]]] | None:
+        """The conditions as a UNION of device filters ([(column, code)] lists), or None when some condition is on a key the
+        device does not code (then the payloads are walked on the host).  MatchValue on a coded key is one code; MatchText on
+        a coded key is every code whose VALUE contains the text -- the dictionaries are small (distinct files, not rows)."""
+        choices: list[list[tuple[int, int]]] = []
+        for key, kind, value in conds:
+            if key not in col.keys:
+                return None
+            c = col.keys.index(key)
+            if kind == "value":
+                code = 0 if value is None else col.codebooks[c].get(_hashable(value))
+                opts = [] if code is None else [(c, code)]
+            else:
+                opts = [(c, code) for v, code in col.codebooks[c].items() if isinstance(v, str) and str(value) in v]
+            choices.append(opts)
+        plans: list[list[tuple[int, int]]] = [[]]
+        for opts in choices:
+            plans = [p + [o] for p in plans for o in opts]
+            if len(plans) > self.MAX_CODE_COMBINATIONS:
+                return None
+        return plans
+
+    def _host_select(self, col: _Collection, conds) -> np.ndarray:
         rows = []
-        for r, p in enumerate(col.payloads):
-            if p is None:
-                continue
+        for r in col.index.match_rows(None, col.index.count()[0]):
+            p = col.payloads[int(r)] or {}
             ok = True
             for key, kind, value in conds:
                 have = p.get(key)
                 ok = ok and ((isinstance(have, str) and str(value) in have) if kind == "text" else have == value)
             if ok:
-                rows.append(r)
-        return rows
+                rows.append(int(r))
+        return np.asarray(rows, dtype=np.int64)
 
     async def count(self, collection_name: str, count_filter=None, exact: bool = True):
-        n = len(await self._store._run(self._select, collection_name, count_filter))
+        def work():
+            col = self._store._col(collection_name)
+            conds = self._conditions(count_filter)
+            plans = self._device_plans(col, conds)
+            if plans is None:
+                return int(self._host_select(col, conds).size)
+            return sum(col.index.count_matching(p) for p in plans)      # (plans differ in at least one code: disjoint)
+        n = await self._store._run(work)
         return type("CountResult", (), {"count": n})()
 
     async def delete(self, collection_name: str, points_selector=None):
@@ -254,7 +339,16 @@ class _RawClient:
 
         def work():
             col = self._store._col(collection_name)
-            col.remove_rows(self._select(collection_name, flt))
+            conds = self._conditions(flt)
+            plans = self._device_plans(col, conds)
+            if plans is None:
+                col.remove_rows(self._host_select(col, conds))
+                return
+            for p in plans:
+                if p:
+                    col.index.tombstone_filter(p)
+                else:                                   # no condition at all: every point
+                    col.remove_rows(col.index.match_rows(None, col.index.count()[0]))
         await self._store._run(work)
 
 
@@ -397,10 +491,11 @@ class HipVectorStore:
             raise VectorStoreError(f"Failed to get collection info for {collection}", cause=e)
 
     # ------------------------------------------------------------------ data path
-    async def upsert(self, collection: str, ids: list[str], vectors: list[list[float]], payloads: list[dict[str, Any]]) -> None:
-        """client.py:115-130.  Same id again replaces the point (Qdrant upsert semantics)."""
+    async def upsert(self, collection: str, ids: list[str], vectors, payloads: list[dict[str, Any]]) -> None:
+        """client.py:115-130.  Same id again replaces the point (Qdrant upsert semantics).  ``vectors``: the reference's
+        list of float lists, or -- without the list round trip -- a float32 ndarray / a CUDA tensor [n, dim]."""
         try:
-            await self._run(lambda: self._col(collection).upsert(list(ids), vectors, list(payloads)))
+            await self._run(lambda: self._col(collection).upsert(ids, vectors, payloads))
             logger.debug(f"Upserted {len(ids)} vectors to {collection}")
         except Exception as e:
             raise VectorStoreError(f"Failed to upsert vectors to {collection}", cause=e)
@@ -422,12 +517,12 @@ class HipVectorStore:
             if query_vector is None:
                 def fetch():
                     col = self._col(collection)
-                    dfilt = col.device_filters(filters)
-                    rows = [] if dfilt is None else col.index.match_rows(dfilt, limit)
-                    return [col.hit(int(r), 0.0) for r in rows]
+                    return [col.hit(int(r), 0.0) for r in col.matching_rows(filters, limit=limit)]
                 results = await self._run(fetch)
             elif len(query_vector) != self._col(collection).index.dim:   # (must not fail the pass it would have joined)
                 raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).index.dim}")
+            elif limit > ffi.MAX_K:                                      # (likewise: only THIS caller is refused)
+                raise ValueError(f"limit {limit} exceeds the index's maximum k of {ffi.MAX_K}")
             elif self._search_coalesce:
                 results = await self._search_coalesced(collection, query_vector, limit, filters)
             else:
@@ -522,10 +617,7 @@ class HipVectorStore:
     async def delete(self, collection: str, filters: dict[str, Any]) -> None:
         """client.py:159-169: delete every point matching the AND of equalities."""
         try:
-            def work():
-                col = self._col(collection)
-                col.remove_rows(col.host_rows(filters))
-            await self._run(work)
+            await self._run(lambda: self._col(collection).delete(filters))
             logger.debug(f"Deleted vectors from {collection} with filters: {filters}")
         except Exception as e:
             raise VectorStoreError(f"Failed to delete from {collection}", cause=e)
@@ -535,10 +627,10 @@ class HipVectorStore:
         try:
             def work():
                 col = self._col(collection)
-                rows = col.host_rows({"file_path": file_path})
-                if not rows:
+                rows = col.matching_rows({"file_path": file_path}, limit=1)
+                if not len(rows):
                     return True
-                return (col.payloads[rows[0]] or {}).get("content_hash") != content_hash
+                return (col.payloads[int(rows[0])] or {}).get("content_hash") != content_hash
             return bool(await self._run(work))
         except Exception as e:
             logger.warning(f"Error checking file update status: {e}")
@@ -546,46 +638,30 @@ class HipVectorStore:
 
     # ------------------------------------------------------------------ persistence
     async def save(self, directory: str) -> None:
-        """Write every collection to ``directory`` (``<name>.npz`` = ids + the STORED, already preprocessed vectors;
-        ``<name>.payloads.json``).  Stands in for the Qdrant volume the reference relies on for restarts
-        (docker-compose.yml:42-43): an indexed project can be reloaded without re-embedding."""
-        import json
-        import os
+        """Write every collection to ``directory/<name>/``: the index image verbatim (raw ``tiles.bin`` the scan's layout,
+        mmap-able; ``alive.u32``; columnar ``codes.i32``; ``master.f32`` for the f32 store) + ``ids.jsonl`` /
+        ``payloads.jsonl`` / ``collection.json``.  No pickle anywhere.  Stands in for the Qdrant volume the reference relies on
+        for restarts (docker-compose.yml:42-43): an indexed project can be reloaded without re-embedding."""
         try:
             def work():
                 os.makedirs(directory, exist_ok=True)
                 for name, col in self._collections.items():
-                    ids, vecs, payloads = col.snapshot()
-                    np.savez(os.path.join(directory, f"{name}.npz"), ids=np.asarray(ids, dtype=object), vectors=vecs,
-                             dtype=np.int32(col.index.dtype), dim=np.int32(col.index.dim))
-                    with open(os.path.join(directory, f"{name}.payloads.json"), "w") as f:
-                        json.dump(payloads, f)
+                    col.save(os.path.join(directory, name))
             await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to save collections to {directory}", cause=e)
 
     async def load(self, directory: str) -> None:
-        """Replace the collections' contents with a snapshot written by :meth:`save`.  Vectors are stored verbatim
-        (``crh_index_append_preprocessed``), so searches return bit-identical scores and the same ids as before."""
-        import json
-        import os
+        """Replace the collections' contents with a snapshot written by :meth:`save`.  The stored image goes back verbatim
+        (``crh_index_import``): searches return bit-identical scores and the same ids as before, deleted rows stay deleted."""
         try:
             await self.clear_collections()
 
             def work():
                 for name, col in self._collections.items():
-                    path = os.path.join(directory, f"{name}.npz")
-                    if not os.path.exists(path):
-                        continue
-                    z = np.load(path, allow_pickle=True)
-                    if int(z["dim"]) != col.index.dim or int(z["dtype"]) != col.index.dtype:
-                        raise ValueError(f"snapshot of {name} is dim {int(z['dim'])} / dtype {int(z['dtype'])}, the store is "
-                                         f"dim {col.index.dim} / dtype {col.index.dtype}")
-                    with open(os.path.join(directory, f"{name}.payloads.json")) as f:
-                        payloads = json.load(f)
-                    ids = [str(i) for i in z["ids"].tolist()]
-                    for s0 in range(0, len(ids), 65536):
-                        col.upsert(ids[s0:s0 + 65536], z["vectors"][s0:s0 + 65536], payloads[s0:s0 + 65536], preprocessed=True)
+                    sub = os.path.join(directory, name)
+                    if os.path.isdir(sub):
+                        col.load(sub)
             await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to load collections from {directory}", cause=e)

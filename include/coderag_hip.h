@@ -93,9 +93,9 @@ int crh_index_destroy(crh_index *h);
 int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device,
                      const int32_t *codes, int64_t *first_row_out, void *stream);
 
-/* Same, for vectors that already went through cosine_preprocess (rows read back with crh_index_read_rows): stored
- * verbatim, so a saved index is restored bit-for-bit.  Replaces what Qdrant's on-disk volume does for the reference
- * (docker-compose.yml:42-43). */
+/* Same, for vectors that already went through cosine_preprocess (rows read back with crh_index_read_rows, and only those:
+ * the scan's exactness margin assumes unit or zero rows): stored verbatim.  (Whole-index snapshots use crh_index_export /
+ * crh_index_import, which move the stored image itself.) */
 int crh_index_append_preprocessed(crh_index *h, int64_t n, const float *vecs, int on_device,
                                   const int32_t *codes, int64_t *first_row_out, void *stream);
 
@@ -103,6 +103,26 @@ int crh_index_append_preprocessed(crh_index *h, int64_t n, const float *vecs, in
  * Replaces the point-removal half of QdrantManager.delete (embeddings/client.py:159-169);
  * which rows a payload filter selects is resolved by the host-side payload table. */
 int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows);
+
+/* Delete by payload filter on the device: every alive row matching ALL the (column == code) predicates stops matching;
+ * n_cleared_out receives how many.  Replaces QdrantManager.delete -> client.delete(FilterSelector(filter))
+ * (embeddings/client.py:159-169) without resolving the filter to row numbers on the host. */
+int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_filters, int64_t *n_cleared_out);
+
+/* Snapshot support -- what Qdrant's on-disk volume does for the reference (docker-compose.yml:42-43): the stored image moves
+ * VERBATIM between HBM and host buffers (typically an mmap of a file) in chunks of 32-row tiles, so a restored index answers
+ * with identical bits.  Per chunk of n_tiles tiles starting at first_tile:
+ *   tiles   n_tiles * (dim/16) KiB  the tiled bf16 image the scan streams
+ *   master  n_tiles * 32 * dim f32  the normalised f32 rows (dtype F32 only; NULL otherwise)
+ *   alive   n_tiles u32             one validity word per tile (tombstones included)
+ *   codes   [n_code_cols][n_tiles*32] int32, column after column (NULL when the index has no code columns)
+ * export: any pointer may be NULL to skip that part.  import: appends at the end of the index (first_tile must be the first
+ * unused tile; capacity must have been reserved), `rows_after` = the row count once this chunk is in (it ends inside the
+ * chunk's last tile). */
+int crh_index_export(crh_index *h, int64_t first_tile, int64_t n_tiles, void *tiles_host, float *master_host,
+                     uint32_t *alive_host, int32_t *codes_host);
+int crh_index_import(crh_index *h, int64_t first_tile, int64_t n_tiles, int64_t rows_after, const void *tiles_host,
+                     const float *master_host, const uint32_t *alive_host, const int32_t *codes_host);
 
 /* rows appended so far / rows still alive (CollectionInfo.points_count, query/engine.py:299-302). */
 int crh_index_count(crh_index *h, int64_t *rows_out, int64_t *alive_out);
@@ -213,7 +233,7 @@ int crh_rerank_vector(int nq, int k, const float *scores_dev, const int64_t *row
                       int32_t *out_count_dev, int32_t *out_flags_dev, void *stream);
 
 /* Filter-only fetch: first `limit` alive rows (ascending) matching the filters, host int64 out;
- * n_out receives how many.  Replaces QdrantManager.search(query_vector=None, ...) as used by
+ * n_out receives how many (rows_out_host may be NULL to count only).  Replaces QdrantManager.search(query_vector=None, ...) as used by
  * query/context/builder.py:111-119 and the scroll of embeddings/client.py:178-202. */
 int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters, int64_t limit,
                          int64_t *rows_out_host, int64_t *n_out);

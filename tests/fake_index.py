@@ -53,5 +53,40 @@ class FakeIndex:
             ok &= self.codes[:, col] == code
         return np.flatnonzero(ok)[:limit].astype(np.int64)
 
+    def _mask(self, filters=None):
+        ok = self.alive.astype(bool).copy()
+        for col, code in (filters or []):
+            ok &= self.codes[:, col] == code
+        return ok
+
+    def count_matching(self, filters=None):
+        return int(self._mask(filters).sum())
+
+    def tombstone_filter(self, filters):
+        assert filters, "a delete needs a filter"
+        m = self._mask(filters)
+        self.alive[m] = 0
+        return int(m.sum())
+
+    def alive_words(self):
+        bits = np.zeros(((len(self.alive) + 31) // 32) * 32, np.uint8)
+        bits[: len(self.alive)] = self.alive
+        return np.packbits(bits, bitorder="little").view(np.uint32).copy()
+
+    def save(self, directory):
+        import os
+        os.makedirs(directory, exist_ok=True)
+        np.save(os.path.join(directory, "fake_x.npy"), self.x)
+        np.save(os.path.join(directory, "fake_alive.npy"), self.alive)
+        np.save(os.path.join(directory, "fake_codes.npy"), self.codes)
+
+    def load(self, directory):
+        import os
+        assert len(self.x) == 0, "load() needs an empty index"
+        self.x = np.load(os.path.join(directory, "fake_x.npy"))
+        self.alive = np.load(os.path.join(directory, "fake_alive.npy"))
+        self.codes = np.load(os.path.join(directory, "fake_codes.npy"))
+        self.capacity_rows = max(self.capacity_rows, (len(self.x) + 31) // 32 * 32)
+
     def close(self):
         self.closed = True

@@ -107,18 +107,33 @@ async def run_store_scenarios(s):
         except VectorStoreError as e:
             assert "Failed to upsert vectors to code_chunks" in str(e)
 
-        # snapshot / restore (stands in for the Qdrant volume): same ids, bit-identical scores, tombstones compacted away
+        # snapshot / restore (stands in for the Qdrant volume): the stored image goes to disk and back VERBATIM -- same ids,
+        # bit-identical scores, deleted points stay deleted, row numbers unchanged; plain files only (raw arrays + JSON lines)
+        import os
         import tempfile
         before = await s.search("code_chunks", q.tolist(), limit=25, filters={"language": "python"})
-        live = (await s.get_collection_info("code_chunks")).points_count
+        info = await s.get_collection_info("code_chunks")
+        live, appended = info.points_count, info.config["rows_appended"]
+        await s.set_graph_degrees("code_chunks", {"mod.ent3": 7})
         with tempfile.TemporaryDirectory() as snap:
             await s.save(snap)
+            names = sorted(os.listdir(os.path.join(snap, "code_chunks")))
+            assert {"ids.jsonl", "payloads.jsonl", "collection.json"} <= set(names)
+            assert not any(n.endswith((".npz", ".pkl", ".pickle")) for n in names)
             await s.load(snap)
-        assert (await s.get_collection_info("code_chunks")).points_count == live
-        assert (await s.get_collection_info("code_chunks")).config["rows_appended"] == live
+        info = await s.get_collection_info("code_chunks")
+        assert info.points_count == live and info.config["rows_appended"] == appended
         assert await s.search("code_chunks", q.tolist(), limit=25, filters={"language": "python"}) == before
         assert await s.file_needs_update("code_chunks", "/proj/f2.py", "hash2") is False
         assert [h["id"] for h in await s.search("summaries", vecs[1].tolist(), limit=2)] == ["s2", "s1"]
+        assert await s.search("code_chunks", None, limit=5, filters={"file_path": "/proj/f1.py"}) == []       # deleted before the save
+        assert s._col("code_chunks")._degrees == {"mod.ent3": 7}
+        # the restored tables are live: the same id again replaces its point, a new value gets a new code
+        keep = before[0]["id"]
+        await s.upsert("code_chunks", [keep], [vecs[0].tolist()], [dict(payloads[0], language="rust")])
+        assert (await s.get_collection_info("code_chunks")).points_count == live
+        got = await s.search("code_chunks", vecs[0].tolist(), limit=3, filters={"language": "rust"})
+        assert [h["id"] for h in got] == [keep]
 
         await s.clear_collections()
         assert (await s.get_collection_info("code_chunks")).points_count == 0

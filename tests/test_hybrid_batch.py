@@ -134,14 +134,15 @@ def test_side_columns_host_coding():
     side = SideColumns(0)
     side.append(payloads[:2])
     side.append(payloads[2:])
-    h = side._host
+    h = {c: v[: side.rows].tolist() for c, v in side._host.items()}          # (the host arrays carry headroom past `rows`)
     assert side.rows == 5 and h["content_len"] == [120, 0, 0, 0, 1]
     assert h["key_code"][0] == h["key_code"][1] != h["key_code"][2]
     assert h["file_code"][0] == h["file_code"][1] and h["file_code"][2] == h["file_code"][4]
     assert h["node_code"][0] == h["node_code"][4] != h["node_code"][1]            # graph_node_id wins over entity_name
     assert h["name_len"] == [9, 9, 0, 0, len(("löwe" + "x" * 70).encode())]
-    assert side._names[0].rstrip(b"\x00") == b"repo.save" and len(side._names[4]) == 64                              # lower-cased, cut to 64 bytes
+    assert side._names[0].tobytes().rstrip(b"\x00") == b"repo.save" and side._names.shape[1] == 64                  # lower-cased, cut to 64 bytes
+    assert side._names[4].tobytes() == ("löwe" + "x" * 70).encode()[:64]
     assert h["degree"] == [-1] * 5
     side.set_degrees({"pkg.Repo.Save": 12, "Repo.Save": 3})
-    assert side._host["degree"] == [12, 3, -1, -1, 12]
+    assert side._host["degree"][:5].tolist() == [12, 3, -1, -1, 12]
     assert node_key(payloads[1]) == "Repo.Save" and merge_key(payloads[2]) == "b.py::None"

@@ -276,7 +276,13 @@ def test_device_rerank_matches_reference_goldens(gpu):
     rows_d, scores_d = torch.from_numpy(rows).to(dev), torch.from_numpy(scores).to(dev)
     # the goldens hand the ranker a ready centrality table for ALL hits (not the engine's first five): centrality_top = k
     out = DeviceReranker(centrality_top=k).rank(scores_d, rows_d, side.gather(rows_d), plans)
+    declined = 0
     for q, (name, s, exp) in enumerate(cases):
+        ents = {e.lower().encode() for e in s["entities"]}
+        if len(ents) > 8 or any(len(e) > 48 for e in ents):          # CRH_RR_MAX_ENTITIES / CRH_RR_ENTITY_BYTES: the host's job
+            assert out.count[q] == -1, name
+            declined += 1
+            continue
         assert out.count[q] == len(exp), (name, out.count[q], len(exp))
         got = DeviceReranker.materialise(out, q, s["vector"])
         got_rows = [[g.entity_name, g.file_path, g.start_line, g.source, g.final_score] + [g.signal_scores[n] for n in SIGNALS] for g in got]
@@ -288,3 +294,4 @@ def test_device_rerank_matches_reference_goldens(gpu):
             assert g[:4] == e[:4], (name, g, e)
             assert np.float32(g[5]) == np.float32(e[5]) and g[6:] == e[6:], (name, g, e)
             assert g[4] == pytest.approx(e[4], rel=0, abs=2e-7), (name, g, e)
+    assert declined <= 12, declined                                   # the long name is drawn as a query entity now and then

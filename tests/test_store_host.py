@@ -93,3 +93,47 @@ def test_concurrent_searches_share_corpus_passes(fake):
     assert passes_lone == 90 and passes_together <= 4
     assert [[(h["id"], h["score"]) for h in r] for r in together] == [[(h["id"], h["score"]) for h in r] for r in lone]
     assert all(len(r) == min(limits[i], n if filts[i] is None else n // 2) for i, r in enumerate(together))
+
+
+def test_limit_above_the_index_maximum_fails_only_its_own_caller(fake):
+    """A limit the index cannot serve (k > 1024) is refused before the query joins a coalesced pass: concurrent searches of
+    other callers still succeed."""
+    async def go():
+        s = store_mod.HipVectorStore(dim=768, initial_capacity=64)
+        async with s:
+            await s.create_collections()
+            rng = np.random.default_rng(0)
+            vecs = rng.standard_normal((20, 768)).astype(np.float32)
+            await s.upsert("code_chunks", [f"i{i}" for i in range(20)], vecs, [{"file_path": "a.py"} for _ in range(20)])
+            res = await asyncio.gather(s.search("code_chunks", vecs[0].tolist(), limit=3),
+                                       s.search("code_chunks", vecs[1].tolist(), limit=5000),
+                                       s.search("code_chunks", vecs[2].tolist(), limit=2), return_exceptions=True)
+            assert len(res[0]) == 3 and len(res[2]) == 2 and res[0][0]["id"] == "i0"
+            assert isinstance(res[1], VectorStoreError) and "1024" in str(res[1])
+    asyncio.run(go())
+
+
+def test_raw_client_matchtext_resolves_through_the_code_dictionaries(fake):
+    """projects/cleanup.py:41-61: count / delete with MatchText on file_path -- every code whose value contains the text."""
+    from types import SimpleNamespace as M
+
+    async def go():
+        s = store_mod.HipVectorStore(dim=768, initial_capacity=64)
+        async with s:
+            await s.create_collections()
+            rng = np.random.default_rng(1)
+            files = [f"/w/projA/f{i % 5}.py" if i % 2 else f"/w/projB/g{i % 3}.py" for i in range(60)]
+            await s.upsert("code_chunks", [f"i{i}" for i in range(60)], rng.standard_normal((60, 768)).astype(np.float32),
+                           [{"file_path": f, "language": "python" if i % 3 else "go"} for i, f in enumerate(files)])
+            flt = M(must=[M(key="file_path", match=M(text="/projA/"))])
+            assert (await s.client.count("code_chunks", count_filter=flt)).count == 30
+            both = M(must=[M(key="file_path", match=M(text="/projA/")), M(key="language", match=M(value="go"))])
+            want = sum(1 for i, f in enumerate(files) if "/projA/" in f and i % 3 == 0)
+            assert (await s.client.count("code_chunks", count_filter=both)).count == want
+            await s.client.delete("code_chunks", points_selector=M(filter=both))
+            assert (await s.client.count("code_chunks", count_filter=flt)).count == 30 - want
+            unc = M(must=[M(key="start_line", match=M(value=None))])               # a key the device does not code: host walk
+            assert (await s.client.count("code_chunks", count_filter=unc)).count == 60 - want
+            await s.client.delete("code_chunks", points_selector=M(filter=M(must=[])))          # no condition: every point
+            assert (await s.get_collection_info("code_chunks")).points_count == 0
+    asyncio.run(go())
