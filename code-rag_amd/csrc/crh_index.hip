@@ -6,6 +6,7 @@
 // if HIP or the device is missing every entry point fails with CRH_E_HIP / CRH_E_NODEVICE.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,7 +44,8 @@ struct Pending {
 
 struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
-    int batch_q = 64;  // queries per scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
+    int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
+    bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -133,9 +135,9 @@ int scan_blocks(const crh_index *h, int64_t nitems)
 int ensure_workspace(crh_index *h, int wave_cap, int qcap)
 {
     const int blocks = h->cu_count;
-    if (!h->qn) CRH_TRY(dev_alloc(&h->qn, (int64_t)kMaxQ * h->dim));
-    if (!h->qfrag) CRH_TRY(dev_alloc(&h->qfrag, (int64_t)2 * h->ksteps * 64));
-    if (!h->tau) CRH_TRY(dev_alloc(&h->tau, kMaxQ));
+    if (!h->qn) CRH_TRY(dev_alloc(&h->qn, (int64_t)kWideQ * h->dim));
+    if (!h->qfrag) CRH_TRY(dev_alloc(&h->qfrag, (int64_t)(kWideQ / 32) * h->ksteps * 64));
+    if (!h->tau) CRH_TRY(dev_alloc(&h->tau, kWideQ));
     if (!h->status) {
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
         CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
@@ -143,7 +145,7 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
     if (h->ws_seed < h->seed_tiles) {
         dev_free(h->gmax);
         h->ws_seed = 0;
-        CRH_TRY(dev_alloc(&h->gmax, (int64_t)h->seed_tiles * kMaxQ));
+        CRH_TRY(dev_alloc(&h->gmax, (int64_t)h->seed_tiles * kWideQ));
         h->ws_seed = h->seed_tiles;
     }
     if (h->ws_mask_tiles < h->cap_tiles) {
@@ -162,13 +164,13 @@ int ensure_workspace(crh_index *h, int wave_cap, int qcap)
         h->ws_wave_cap = wave_cap;
     }
     if (h->ws_qcap != qcap) {
-        const int64_t bytes = (int64_t)kMaxQ * qcap * 16;
+        const int64_t bytes = (int64_t)kWideQ * qcap * 16;
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "per-query candidate lists of %lld bytes exceed the budget", (long long)bytes);
         dev_free(h->qlist);
         dev_free(h->skeys);
         h->ws_qcap = 0;
-        CRH_TRY(dev_alloc(&h->qlist, (int64_t)kMaxQ * qcap));
-        CRH_TRY(dev_alloc(&h->skeys, (int64_t)kMaxQ * qcap));
+        CRH_TRY(dev_alloc(&h->qlist, (int64_t)kWideQ * qcap));
+        CRH_TRY(dev_alloc(&h->skeys, (int64_t)kWideQ * qcap));
         h->ws_qcap = qcap;
     }
     return CRH_OK;
@@ -225,7 +227,26 @@ int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, 
     return CRH_OK;
 }
 
-// one <= 64-query batch, everything enqueued on `st`
+// the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
+template <int MODE>
+int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
+                     SearchStatus *stt)
+{
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
+#define CRH_WIDE(KS)                                                                                                              \
+    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(512), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
+                       h->gmax, kWideQ, h->wave_lists, kWaves, wave_cap, stt->qcount, h->qlist, qcap, stt)
+    switch (h->ksteps) {
+    case 24: CRH_WIDE(24); break;
+    case 48: CRH_WIDE(48); break;
+    default: return fail(CRH_E_INTERNAL, "no wide scan kernel for %d k-steps", h->ksteps);
+    }
+#undef CRH_WIDE
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+// one batch (<= batch_q queries through k_scan, or up to kWideQ through k_scan_wide), everything enqueued on `st`
 int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
                   int64_t *out_r, int slot, hipStream_t st)
 {
@@ -240,20 +261,31 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     const int wave_cap = h->ws_wave_cap, qcap = h->ws_qcap;
     const float margin = margin_for(h);
     SearchStatus *stt = h->status + slot;
+    const bool wide = nq > h->batch_q;
+    if (wide && (!h->wide_ok || nq > kWideQ)) return fail(CRH_E_INTERNAL, "batch of %d queries has no scan kernel", nq);
+    const int nblk = (nq + 31) / 32;                       // 32-query blocks in use (wide scan)
+    const int width = wide ? nblk * 32 : h->batch_q;       // query slots prepared (slots >= nq are zero queries, tau = +inf)
+    const int qstride = wide ? kWideQ : 64;                // row pitch of the seed maxima
 
     if (h->dtype == CRH_DTYPE_BF16)
-        hipLaunchKernelGGL(k_prep_queries<true>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
     else
-        hipLaunchKernelGGL(k_prep_queries<false>, dim3(h->batch_q), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
     CRH_HIP(hipGetLastError());
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
-    CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
-    hipLaunchKernelGGL(k_tau, dim3(h->batch_q), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau);
+    if (wide)
+        CRH_TRY(launch_scan_wide<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
+    else
+        CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
+    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau, qstride);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
-    CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
+    if (wide)
+        CRH_TRY(launch_scan_wide<1>(h, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
+    else
+        CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
         hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, stt->qcount, qcap, h->skeys, h->qn, h->xt,
@@ -369,6 +401,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     h->dim = dim;
     h->ksteps = dim / 16;
     h->batch_q = dim > 1024 ? 32 : 64;
+    h->wide_ok = dim <= 768 && getenv("CODERAG_HIP_NO_WIDE_SCAN") == nullptr;   // (the env switch exists for A/B timing only)
     h->dtype = dtype;
     h->ncols = n_code_cols;
     h->device = device;
@@ -759,8 +792,10 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
 
     const uint32_t *mask = nullptr;
     CRH_TRY(build_mask(h, filters, n_filters, &mask, st));
-    for (int q0 = 0; q0 < nq; q0 += h->batch_q) {
-        const int b = std::min(h->batch_q, nq - q0);
+    // more than one k_scan pass worth of queries: up to kWideQ of them share ONE corpus pass through k_scan_wide
+    for (int q0 = 0, b = 0; q0 < nq; q0 += b) {
+        const int left = nq - q0;
+        b = (h->wide_ok && left > h->batch_q) ? std::min(kWideQ, left) : std::min(h->batch_q, left);
         if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
         Pending p{};
         p.nq = b;

@@ -27,7 +27,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int kTileRows = 32;
-constexpr int kMaxQ = 64;  // queries per scan pass (two 32-column MFMA B blocks)
+constexpr int kMaxQ = 64;   // queries per pass of the LDS-query scan k_scan (two 32-column MFMA B blocks)
+constexpr int kWideQ = 256;  // queries per pass of the register-query scan k_scan_wide (eight waves x one 32-column block)
 
 struct SearchStatus {
     unsigned int max_wave_cnt;  // largest per-wave candidate count (unclamped)
@@ -36,7 +37,7 @@ struct SearchStatus {
     unsigned int q_overflow;
     unsigned long long candidates;
     unsigned long long pad_;
-    unsigned int qcount[kMaxQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
+    unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -491,6 +492,178 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     }
 }
 
+// ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
+
+// k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
+// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: each of a workgroup's
+// 8 waves keeps ONE 32-query block as MFMA B fragments in its own registers for the whole kernel (KSTEPS x 4 VGPRs: 192 at
+// dim 768 -- two waves per SIMD at 256 registers each), and the CORPUS tiles go through LDS: a ring of SLOTS tiles filled by
+// LDS-DMA (global_load_lds_dwordx4, nt; every wave issues KSTEPS/8 of a tile's 1-KiB pieces), read back by all 8 waves with
+// one conflict-free ds_read_b128 per MFMA.  One corpus pass then serves 256 queries: HBM bytes per query / 4, 96 MFMAs of
+// 32x32x16 per SIMD per tile (3072 cycles) against ~4.9k cycles of HBM time per 48-KB tile per CU -- still HBM-bound.
+// Per tile: ONE raw s_barrier -- each wave first waits (counted vmcnt) for its own pieces of tile j, so after the barrier
+// tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
+// issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's (one 32-query
+// block per wave instead of two).  nblk = number of 32-query blocks in use: waves beyond it only move data.
+template <int N>
+__device__ __forceinline__ void vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(512) void k_scan_wide(
+    const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
+    const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax, int qstride,
+    u32x4 *__restrict__ wave_lists, int lists_per_block, int wave_cap, unsigned int *__restrict__ qcount,
+    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
+{
+    constexpr int WAVES = 8;
+    constexpr int PPW = KSTEPS / WAVES;                   // 1-KiB pieces of a tile issued by each wave
+    constexpr int SLOTS = (KSTEPS * 3 <= 144) ? 3 + (144 - KSTEPS * 3) / KSTEPS : 3;   // 144 KB of LDS: 3 tiles at dim 768, 6 at 384
+    static_assert(KSTEPS % WAVES == 0 && SLOTS >= 3 && SLOTS * KSTEPS <= 144, "ring geometry");
+    __shared__ u32x4 ring[SLOTS * KSTEPS * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const bool active = wave < nblk;
+
+    u32x4 qreg[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    float t0 = 0.f;
+    if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
+
+    const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
+    unsigned int wcnt = 0;
+
+    auto issue = [&](int j) {
+        const int64_t tile = (int64_t)((int)blockIdx.x + j * (int)gridDim.x) * tile_stride;
+        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
+        u32x4 *dst = ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
+    };
+    for (int j = 0; j < SLOTS - 1 && j < nmine; ++j) issue(j);
+
+    for (int j = 0; j < nmine; ++j) {
+        // my pieces of tile j have landed once at most min(SLOTS-2, tiles after j) later tiles of mine are still in flight
+        const int ahead = (nmine - 1 - j) < (SLOTS - 2) ? (nmine - 1 - j) : (SLOTS - 2);
+        if (ahead >= 4) vm_wait<4 * PPW>();
+        else if (ahead == 3) vm_wait<3 * PPW>();
+        else if (ahead == 2) vm_wait<2 * PPW>();
+        else if (ahead == 1) vm_wait<PPW>();
+        else vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + SLOTS - 1 < nmine) issue(j + SLOTS - 1);   // into the slot tile j-1 was read from: free since the barrier
+
+        if (!active) continue;
+        const int item = (int)blockIdx.x + j * (int)gridDim.x;
+        const int64_t tile = (int64_t)item * tile_stride;
+        const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
+        const u32x4 *lp = ring + (size_t)(j % SLOTS) * KSTEPS * 64 + lane;
+        // 192 of the wave's 256 registers hold its queries: the corpus fragments get a 4-deep rotation (three ds_read_b128 in
+        // flight ahead of the MFMA that consumes the fourth), enough to cover the LDS latency behind 32-cycle MFMAs
+        f32x16 a0 = {0};
+        u32x4 af[4];
+        af[0] = lp[0];
+        af[1] = lp[64];
+        af[2] = lp[128];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + 3 < KSTEPS) af[(s + 3) & 3] = lp[(s + 3) * 64];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s & 3]), __builtin_bit_cast(bf16x8, qreg[s]), a0, 0, 0, 0);
+        }
+
+        if (MODE == 0) {
+            float m0 = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? a0[r] : -INFINITY);
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            if (h == 0) gmax[(size_t)item * qstride + wave * 32 + lane] = m0;
+        } else {
+            float m0 = a0[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, a0[r]);
+            if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
+                uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
+                asm volatile("" : "+v"(rowbase));   // keep the 16 row numbers out of the loop-invariant registers (rare path)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    const int rbit = row + 4 * h;
+                    const float sc = a0[r];
+                    const bool pass = ((vmask >> rbit) & 1u) && (sc >= t0);
+                    const unsigned long long pm = __ballot(pass);
+                    if (pm != 0ull) {
+                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                        const unsigned int pos = wcnt + pre;
+                        if (pass && pos < (unsigned int)wave_cap) {
+                            u32x4 e;
+                            e.x = f32_bits(sc);
+                            e.y = rowbase + row;
+                            e.z = (uint32_t)(wave * 32 + (lane & 31));
+                            e.w = 0u;
+                            mylist[pos] = e;
+                        }
+                        wcnt += (unsigned int)__popcll(pm);
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (MODE == 1) {
+        // hand the workgroup's candidates over to the per-query lists (as k_scan does, 256 bins)
+        __syncthreads();   // every wave is done with the ring, and its list stores have completed
+        unsigned int *wc = reinterpret_cast<unsigned int *>(ring);   // [WAVES] counts, [256] hist, [256] base, [256] off
+        unsigned int *hist = wc + WAVES;
+        unsigned int *base = hist + kWideQ;
+        unsigned int *off = base + kWideQ;
+        if (lane == 0) {
+            wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+            atomicMax(&status->max_wave_cnt, wcnt);
+            if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
+        }
+        if (tid < kWideQ) {
+            hist[tid] = 0u;
+            off[tid] = 0u;
+        }
+        __syncthreads();
+        const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & (kWideQ - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid < kWideQ) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
+        __syncthreads();
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) {
+                const u32x4 c = wl[(size_t)w * wave_cap + e];
+                const unsigned int q = c.z & (kWideQ - 1);
+                const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+                if (idx < (unsigned int)qcap) {
+                    u32x2 o;
+                    o.x = c.x;
+                    o.y = c.y;
+                    qlist[(size_t)q * qcap + idx] = o;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ workgroup-wide selection helpers
 
 // k-th largest (1-based) of n keys fetched by get(i), by MSB-first 8-bit radix passes.
@@ -602,7 +775,7 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
 // sampled tiles hold a valid row; +inf for the padding columns q >= nq of a short batch (they nominate nothing).  Any k tiles each contribute >= 1 row at or above their maximum, so
 // at least k valid rows score >= the k-th largest maximum: it is a lower bound of the true k-th score.
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int G, int k, float margin, int nq,
-                                             float *__restrict__ tau)
+                                             float *__restrict__ tau, int qstride)
 {
     extern __shared__ uint32_t col[];  // [G] ordered keys of this query's tile maxima
     __shared__ unsigned int hist[4 * 256];
@@ -612,7 +785,7 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
     if (q >= nq) {   // block-uniform
         t = INFINITY;
     } else if (G >= k) {
-        for (int i = threadIdx.x; i < G; i += 256) col[i] = ord_f32(gmax[(size_t)i * 64 + q]);
+        for (int i = threadIdx.x; i < G; i += 256) col[i] = ord_f32(gmax[(size_t)i * qstride + q]);
         __syncthreads();
         const uint32_t key = wg_kth_largest<uint32_t, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k, hist, bcast);
         t = unord_f32(key);

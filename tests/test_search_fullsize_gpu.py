@@ -5,7 +5,8 @@ need a 10M-row CPU scan:
   * shards     : two 5M-row shards searched separately and merged by crh_merge_topk == the 10M-row search, bit for bit
                  (the 8-GPU configuration in miniature);
   * filter     : a payload filter selecting 1M of the rows == the oracle run on exactly those 1M rows;
-  * idempotent : the same search twice gives identical bytes.
+  * idempotent : the same search twice gives identical bytes;
+  * wide       : a 512-query call (two passes of k_scan_wide) == the same queries searched 64 at a time.
 """
 import numpy as np
 import pytest
@@ -71,6 +72,16 @@ def test_full_size_properties(gpu):
     ffi.merge_topk(ps, pr, ms, mr)
     torch.cuda.synchronize()
     assert np.array_equal(mr.cpu().numpy(), r) and np.array_equal(ms.cpu().numpy().view(np.uint32), s.view(np.uint32))
+
+    # 512 queries in one call = two passes of the wide scan == the same queries 64 at a time, bit for bit
+    big = np.concatenate([q, rng.standard_normal((512 - NQ, D)).astype(np.float32)])
+    bs, br = full.search(big, K)
+    assert full.stats()["batches"] == 2 and full.stats()["fallback_used"] == 0
+    assert np.array_equal(br[:NQ], r) and np.array_equal(bs[:NQ].view(np.uint32), s.view(np.uint32))
+    for q0 in (64, 256, 448):
+        ps_, pr_ = full.search(big[q0:q0 + 64], K)
+        assert np.array_equal(br[q0:q0 + 64], pr_) and np.array_equal(bs[q0:q0 + 64].view(np.uint32), ps_.view(np.uint32))
+    assert np.all((bs[:, :-1] > bs[:, 1:]) | ((bs[:, :-1] == bs[:, 1:]) & (br[:, :-1] < br[:, 1:])))
 
     # filter == oracle on the selected 1M rows (8 queries keep the CPU side to a few seconds)
     fs, fr = full.search(q[8:16], K, filters=[(0, 3)])

@@ -336,16 +336,16 @@ def test_clustered_corpus_with_near_duplicate_scores(gpu, bf16):
 
 
 def test_randomised_configurations_against_the_oracle(gpu):
-    """40 seeded random configurations -- width, store precision, row count (down to 1), query count (across the 64-query
-    pass boundary), k (beyond the row count too), tombstones, a payload filter, duplicated rows (exact ties), zero rows,
+    """60 seeded random configurations -- width, store precision, row count (down to 1), query count (across the 64-query
+    pass boundary and the 256-query one of the wide scan), k (beyond the row count too), tombstones, a payload filter, duplicated rows (exact ties), zero rows,
     a non-zero row_base, appends in several pieces -- each compared bit for bit with the oracle."""
     ffi = _ffi()
     rng = np.random.default_rng(2026)
-    for case in range(40):
+    for case in range(60):
         dim = int(rng.choice([384, 768, 768, 768, 1024, 1536]))
         bf16 = bool(rng.integers(0, 2))
         n = int(rng.choice([1, 2, 31, 32, 33, 100, 1000, 4097, int(rng.integers(5000, 30000))]))
-        nq = int(rng.choice([1, 2, 31, 64, 65, 100, 130]))
+        nq = int(rng.choice([1, 2, 31, 64, 65, 100, 130, 256, 257, 512, 700]))
         k = int(rng.choice([1, 5, 10, 100, 257]))
         x = rng.standard_normal((n, dim), dtype=np.float32) * rng.uniform(0.2, 5.0, size=(n, 1)).astype(np.float32)
         if n > 10:
@@ -431,3 +431,57 @@ def test_merge_out_of_the_packed_exchange_buffer(gpu, world, nq, k):
     if nq > 1 and k > 1:
         with pytest.raises(ffi.NativeError):                 # lists that are not contiguous are refused, not misread
             ffi.merge_topk(all_s.transpose(1, 2), all_r, ms, mr, 0)
+
+
+# ---- the wide scan (k_scan_wide: 65 .. 256 queries share ONE corpus pass, query fragments in registers, corpus through LDS)
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("dim,n,nq,k", [(768, 20000, 300, 100), (768, 4099, 65, 10), (384, 9000, 256, 50), (768, 50000, 96, 1000), (768, 31, 200, 5)])
+def test_wide_scan_against_the_oracle(gpu, bf16, dim, n, nq, k):
+    ffi = _ffi()
+    rng = np.random.default_rng(n + nq)
+    x = rng.standard_normal((n, dim), dtype=np.float32) * rng.uniform(0.2, 5.0, size=(n, 1)).astype(np.float32)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    q[nq // 2] = x[n // 3] * 2.0
+    codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
+    idx = ffi.Index(dim, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n, n_code_cols=1)
+    idx.append(x, codes)
+    dead = rng.choice(n, n // 7, replace=False)
+    idx.tombstone(dead)
+    alive = np.ones(n, bool)
+    alive[dead] = False
+    for filt in (None, [(0, 2)]):
+        s, r = idx.search(q, k, filters=filt, row_base=5)
+        es, er = orc.cosine_search(x, q, k, bf16=bf16, alive=alive, codes=codes, filters=filt)
+        assert np.array_equal(r, np.where(er >= 0, er + 5, er)) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    st = idx.stats()
+    assert st["batches"] == (nq + 255) // 256, st          # ONE pass per 256 queries, not one per 64
+    idx.close()
+
+
+def test_wide_scan_equals_the_64_query_passes_and_survives_overflow(gpu, monkeypatch):
+    """The two scans nominate through different arithmetic orders; the canonical re-score decides both: identical bytes.
+    Also through the regrow path (absurdly small candidate buffers first)."""
+    ffi = _ffi()
+    rng = np.random.default_rng(77)
+    n, nq, k = 60000, 250, 100
+    x = rng.standard_normal((n, D), dtype=np.float32)
+    x[1000:1400] = x[7] + 1e-3 * rng.standard_normal((400, D), dtype=np.float32)      # a dense cluster: many near ties
+    q = rng.standard_normal((nq, D), dtype=np.float32)
+    q[3] = x[7]
+    wide = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n)
+    wide.append(x)
+    ws, wr = wide.search(q, k)
+    assert wide.stats()["batches"] == 1
+    monkeypatch.setenv("CODERAG_HIP_NO_WIDE_SCAN", "1")
+    narrow = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n)
+    monkeypatch.delenv("CODERAG_HIP_NO_WIDE_SCAN")
+    narrow.append(x)
+    ns, nr = narrow.search(q, k)
+    assert narrow.stats()["batches"] == 4
+    assert np.array_equal(wr, nr) and np.array_equal(ws.view(np.uint32), ns.view(np.uint32))
+    wide.set_tuning(force_fallback=1)
+    fs, fr = wide.search(q, k)
+    assert wide.stats()["fallback_used"] == 1
+    assert np.array_equal(fr, wr) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
+    wide.close()
+    narrow.close()

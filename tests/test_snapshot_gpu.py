@@ -55,6 +55,7 @@ def test_index_save_load_is_bit_identical(gpu, tmp_path, dtype_name, dim, rows):
     es, er = orc.cosine_search(x, q, 50, bf16=(dtype_name == "bf16"), alive=alive, codes=codes, filters=[(0, 1)])
     assert np.array_equal(got[1][1], er) and np.array_equal(got[1][0].view(np.uint32), es.view(np.uint32))
     # the restored index keeps growing: appends continue after the last restored row
+    b.reserve(rows + 5)
     first = b.append(x[:5], codes[:5])
     assert first == rows and b.count() == (rows + 5, rows - len(dead) + 5)
     # wrong geometry is refused, loudly
