@@ -234,7 +234,7 @@ int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nit
 {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
 #define CRH_WIDE(KS)                                                                                                              \
-    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(512), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
+    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
                        h->gmax, kWideQ, h->wave_lists, kWaves, wave_cap, stt->qcount, h->qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_WIDE(24); break;

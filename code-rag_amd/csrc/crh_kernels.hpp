@@ -495,16 +495,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
 
 // k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
-// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: each of a workgroup's
-// 8 waves keeps ONE 32-query block as MFMA B fragments in its own registers for the whole kernel (KSTEPS x 4 VGPRs: 192 at
-// dim 768 -- two waves per SIMD at 256 registers each), and the CORPUS tiles go through LDS: a ring of SLOTS tiles filled by
-// LDS-DMA (global_load_lds_dwordx4, nt; every wave issues KSTEPS/8 of a tile's 1-KiB pieces), read back by all 8 waves with
-// one conflict-free ds_read_b128 per MFMA.  One corpus pass then serves 256 queries: HBM bytes per query / 4, 96 MFMAs of
-// 32x32x16 per SIMD per tile (3072 cycles) against ~4.9k cycles of HBM time per 48-KB tile per CU -- still HBM-bound.
+// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: a workgroup is 4 waves,
+// ONE per SIMD with the SIMD's whole 512-register file, and each wave keeps TWO 32-query blocks as MFMA B fragments in its
+// registers for the whole kernel (2 x KSTEPS x 4 = 384 registers at dim 768).  The CORPUS tiles go through LDS: a ring of
+// SLOTS tiles filled by LDS-DMA (global_load_lds_dwordx4, nt; every wave issues KSTEPS/4 of a tile's 1-KiB pieces), read
+// back by all 4 waves with one conflict-free ds_read_b128 per TWO MFMAs, PF reads ahead of the MFMAs that consume them (the
+// registers left over pay for that: with 8 waves of 256 registers and one read per MFMA the LDS latency was exposed and the
+// pass took 4.0 ms; profiles/r02_wide_scan.md).  One corpus pass serves 256 queries: HBM bytes per query / 4; per tile and
+// SIMD 96 MFMAs of 32x32x16 = 3072 cycles against ~4.9k cycles of HBM time per 48-KB tile per CU.
 // Per tile: ONE raw s_barrier -- each wave first waits (counted vmcnt) for its own pieces of tile j, so after the barrier
 // tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
-// issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's (one 32-query
-// block per wave instead of two).  nblk = number of 32-query blocks in use: waves beyond it only move data.
+// issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's.
+// nblk = number of 32-query blocks in use: a wave whose blocks are both unused only moves data.
 template <int N>
 __device__ __forceinline__ void vm_wait()
 {
@@ -512,28 +514,35 @@ __device__ __forceinline__ void vm_wait()
 }
 
 template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(512) void k_scan_wide(
+__global__ __launch_bounds__(256) void k_scan_wide(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
     const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax, int qstride,
     u32x4 *__restrict__ wave_lists, int lists_per_block, int wave_cap, unsigned int *__restrict__ qcount,
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
-    constexpr int WAVES = 8;
+    constexpr int WAVES = 4;
     constexpr int PPW = KSTEPS / WAVES;                   // 1-KiB pieces of a tile issued by each wave
     constexpr int SLOTS = (KSTEPS * 3 <= 144) ? 3 + (144 - KSTEPS * 3) / KSTEPS : 3;   // 144 KB of LDS: 3 tiles at dim 768, 6 at 384
-    static_assert(KSTEPS % WAVES == 0 && SLOTS >= 3 && SLOTS * KSTEPS <= 144, "ring geometry");
+    constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
+    static_assert(KSTEPS % WAVES == 0 && SLOTS >= 3 && SLOTS * KSTEPS <= 144 && KSTEPS > PF, "ring geometry");
     __shared__ u32x4 ring[SLOTS * KSTEPS * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const bool active = wave < nblk;
+    const bool act0 = 2 * wave < nblk, act1 = 2 * wave + 1 < nblk;
 
-    u32x4 qreg[KSTEPS];
+    u32x4 q0[KSTEPS], q1[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-    float t0 = 0.f;
-    if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
+    for (int s = 0; s < KSTEPS; ++s) {
+        q0[s] = act0 ? qfrag[((size_t)(2 * wave) * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+        q1[s] = act1 ? qfrag[((size_t)(2 * wave + 1) * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    }
+    float t0 = 0.f, t1 = 0.f;
+    if (MODE == 1) {
+        t0 = act0 ? tau[wave * 64 + (lane & 31)] : INFINITY;
+        t1 = act1 ? tau[wave * 64 + 32 + (lane & 31)] : INFINITY;
+    }
 
     const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
@@ -562,59 +571,82 @@ __global__ __launch_bounds__(512) void k_scan_wide(
         asm volatile("" ::: "memory");
         if (j + SLOTS - 1 < nmine) issue(j + SLOTS - 1);   // into the slot tile j-1 was read from: free since the barrier
 
-        if (!active) continue;
+        if (!act0) continue;
         const int item = (int)blockIdx.x + j * (int)gridDim.x;
         const int64_t tile = (int64_t)item * tile_stride;
         const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
         const u32x4 *lp = ring + (size_t)(j % SLOTS) * KSTEPS * 64 + lane;
-        // 192 of the wave's 256 registers hold its queries: the corpus fragments get a 4-deep rotation (three ds_read_b128 in
-        // flight ahead of the MFMA that consumes the fourth), enough to cover the LDS latency behind 32-cycle MFMAs
-        f32x16 a0 = {0};
-        u32x4 af[4];
-        af[0] = lp[0];
-        af[1] = lp[64];
-        af[2] = lp[128];
+        f32x16 a0 = {0}, a1 = {0};
+        u32x4 af[PF + 1];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            if (s + 3 < KSTEPS) af[(s + 3) & 3] = lp[(s + 3) * 64];
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s & 3]), __builtin_bit_cast(bf16x8, qreg[s]), a0, 0, 0, 0);
+        for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
+        if (act1) {   // (two straight-line bodies: a wave-uniform branch per k-step would cut the schedule into 48 pieces)
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q1[s]), a1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s % (PF + 1)]), __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         if (MODE == 0) {
-            float m0 = -INFINITY;
+            float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? a0[r] : -INFINITY);
+                const bool ok = (vmask >> row) & 1u;
+                m0 = fmaxf(m0, ok ? a0[r] : -INFINITY);
+                m1 = fmaxf(m1, ok ? a1[r] : -INFINITY);
             }
             m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            if (h == 0) gmax[(size_t)item * qstride + wave * 32 + lane] = m0;
+            m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            if (h == 0) {
+                gmax[(size_t)item * qstride + wave * 64 + lane] = m0;
+                if (act1) gmax[(size_t)item * qstride + wave * 64 + 32 + lane] = m1;
+            }
         } else {
-            float m0 = a0[0];
+            float m0 = a0[0], m1 = a1[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, a0[r]);
-            if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
+            for (int r = 1; r < 16; ++r) {
+                m0 = fmaxf(m0, a0[r]);
+                m1 = fmaxf(m1, a1[r]);
+            }
+            const bool any = (m0 >= t0) || (m1 >= t1);
+            if (__ballot(any) != 0ull && vmask != 0u) {
                 uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
                 asm volatile("" : "+v"(rowbase));   // keep the 16 row numbers out of the loop-invariant registers (rare path)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    const int rbit = row + 4 * h;
-                    const float sc = a0[r];
-                    const bool pass = ((vmask >> rbit) & 1u) && (sc >= t0);
-                    const unsigned long long pm = __ballot(pass);
-                    if (pm != 0ull) {
-                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-                        const unsigned int pos = wcnt + pre;
-                        if (pass && pos < (unsigned int)wave_cap) {
-                            u32x4 e;
-                            e.x = f32_bits(sc);
-                            e.y = rowbase + row;
-                            e.z = (uint32_t)(wave * 32 + (lane & 31));
-                            e.w = 0u;
-                            mylist[pos] = e;
+                for (int qb = 0; qb < 2; ++qb) {
+                    const float tq = qb ? t1 : t0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        const int rbit = row + 4 * h;
+                        const float sc = qb ? a1[r] : a0[r];
+                        const bool pass = ((vmask >> rbit) & 1u) && (sc >= tq);
+                        const unsigned long long pm = __ballot(pass);
+                        if (pm != 0ull) {
+                            const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                            const unsigned int pos = wcnt + pre;
+                            if (pass && pos < (unsigned int)wave_cap) {
+                                u32x4 e;
+                                e.x = f32_bits(sc);
+                                e.y = rowbase + row;
+                                e.z = (uint32_t)(wave * 64 + qb * 32 + (lane & 31));
+                                e.w = 0u;
+                                mylist[pos] = e;
+                            }
+                            wcnt += (unsigned int)__popcll(pm);
                         }
-                        wcnt += (unsigned int)__popcll(pm);
                     }
                 }
             }
@@ -634,10 +666,8 @@ __global__ __launch_bounds__(512) void k_scan_wide(
             atomicMax(&status->max_wave_cnt, wcnt);
             if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
         }
-        if (tid < kWideQ) {
-            hist[tid] = 0u;
-            off[tid] = 0u;
-        }
+        hist[tid] = 0u;      // 256 threads, 256 bins
+        off[tid] = 0u;
         __syncthreads();
         const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
         for (int w = 0; w < WAVES; ++w) {
@@ -645,7 +675,7 @@ __global__ __launch_bounds__(512) void k_scan_wide(
             for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & (kWideQ - 1)], 1u);
         }
         __syncthreads();
-        if (tid < kWideQ) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
+        base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
         __syncthreads();
         for (int w = 0; w < WAVES; ++w) {
             const unsigned int n = wc[w];
