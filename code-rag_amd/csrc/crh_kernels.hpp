@@ -548,30 +548,41 @@ __global__ __launch_bounds__(256) void k_scan_wide(
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
     unsigned int wcnt = 0;
 
-    auto issue = [&](int j) {
-        const int64_t tile = (int64_t)((int)blockIdx.x + j * (int)gridDim.x) * tile_stride;
-        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
-        u32x4 *dst = ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64;
-#pragma unroll
-        for (int p = 0; p < PPW; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
-                                             (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
+    // piece p (0 .. PPW-1) of this wave's share of tile j: one 1-KiB LDS-DMA
+    auto issue_piece = [&](const u32x4 *src, u32x4 *dst, int p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+                                         (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
     };
-    for (int j = 0; j < SLOTS - 1 && j < nmine; ++j) issue(j);
+    // tile j of this workgroup, clamped to its last one: past the end the ring is refilled with a tile nobody reads, so that
+    // every iteration issues the same PPW pieces and the counted wait is ONE constant (no per-piece branches in the MFMA stream)
+    auto src_of = [&](int j) {
+        const int jj = j < nmine ? j : nmine - 1;
+        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
+        return xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
+    };
+    auto dst_of = [&](int j) { return ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64; };
+    auto issue = [&](int j) {
+        const u32x4 *src = src_of(j);
+        u32x4 *dst = dst_of(j);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) issue_piece(src, dst, p);
+    };
+    if (nmine > 0)
+        for (int j = 0; j < SLOTS - 1; ++j) issue(j);
 
     for (int j = 0; j < nmine; ++j) {
-        // my pieces of tile j have landed once at most min(SLOTS-2, tiles after j) later tiles of mine are still in flight
-        const int ahead = (nmine - 1 - j) < (SLOTS - 2) ? (nmine - 1 - j) : (SLOTS - 2);
-        if (ahead >= 4) vm_wait<4 * PPW>();
-        else if (ahead == 3) vm_wait<3 * PPW>();
-        else if (ahead == 2) vm_wait<2 * PPW>();
-        else if (ahead == 1) vm_wait<PPW>();
-        else vm_wait<0>();
+        vm_wait<(SLOTS - 2) * PPW>();   // my pieces of tile j have landed; those of the SLOTS-2 tiles after it may be in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j + SLOTS - 1 < nmine) issue(j + SLOTS - 1);   // into the slot tile j-1 was read from: free since the barrier
-
-        if (!act0) continue;
+        // tile j+SLOTS-1 goes into the slot tile j-1 was read from (free since the barrier).  A wave with one wave per SIMD has
+        // nobody to hide a burst of PPW DMA issues behind: the pieces are issued BETWEEN the MFMAs below, one every WAVES
+        // k-steps (all at once only by a wave that computes nothing)
+        const u32x4 *rsrc = src_of(j + SLOTS - 1);
+        u32x4 *rdst = dst_of(j + SLOTS - 1);
+        if (!act0) {
+            issue(j + SLOTS - 1);
+            continue;
+        }
         const int item = (int)blockIdx.x + j * (int)gridDim.x;
         const int64_t tile = (int64_t)item * tile_stride;
         const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
@@ -587,6 +598,7 @@ __global__ __launch_bounds__(256) void k_scan_wide(
                 const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q1[s]), a1, 0, 0, 0);
+                if (s % WAVES == 1) issue_piece(rsrc, rdst, s / WAVES);
                 __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
             }
         } else {
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(256) void k_scan_wide(
             for (int s = 0; s < KSTEPS; ++s) {
                 if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s % (PF + 1)]), __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
+                if (s % WAVES == 1) issue_piece(rsrc, rdst, s / WAVES);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

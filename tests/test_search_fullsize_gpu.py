@@ -76,7 +76,7 @@ def test_full_size_properties(gpu):
     # 512 queries in one call = two passes of the wide scan == the same queries 64 at a time, bit for bit
     big = np.concatenate([q, rng.standard_normal((512 - NQ, D)).astype(np.float32)])
     bs, br = full.search(big, K)
-    assert full.stats()["batches"] == 2 and full.stats()["fallback_used"] == 0
+    assert full.stats()["batches"] == 2 and full.stats()["fallback_used"] == 0, full.stats()
     assert np.array_equal(br[:NQ], r) and np.array_equal(bs[:NQ].view(np.uint32), s.view(np.uint32))
     for q0 in (64, 256, 448):
         ps_, pr_ = full.search(big[q0:q0 + 64], K)
