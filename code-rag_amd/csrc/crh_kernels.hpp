@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace crh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -521,11 +523,13 @@ __global__ __launch_bounds__(256) void k_scan_wide(
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
     constexpr int WAVES = 4;
-    constexpr int PPW = KSTEPS / WAVES;                   // 1-KiB pieces of a tile issued by each wave
-    constexpr int SLOTS = (KSTEPS * 3 <= 144) ? 3 + (144 - KSTEPS * 3) / KSTEPS : 3;   // 144 KB of LDS: 3 tiles at dim 768, 6 at 384
+    constexpr int CH = 12;                                 // k-steps (1-KiB pieces) per ring chunk
+    constexpr int NCH = KSTEPS / CH;                       // chunks per tile
+    constexpr int RING = 144 / CH;                         // 12 chunks = 144 KB of LDS = 3 tiles at dim 768, 6 at dim 384
+    constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
     constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
-    static_assert(KSTEPS % WAVES == 0 && SLOTS >= 3 && SLOTS * KSTEPS <= 144 && KSTEPS > PF, "ring geometry");
-    __shared__ u32x4 ring[SLOTS * KSTEPS * 64];
+    static_assert(KSTEPS % CH == 0 && RING % NCH == 0 && CH % WAVES == 0 && KSTEPS > PF, "ring geometry");
+    __shared__ u32x4 ring[RING * CH * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -548,68 +552,82 @@ __global__ __launch_bounds__(256) void k_scan_wide(
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
     unsigned int wcnt = 0;
 
-    // piece p (0 .. PPW-1) of this wave's share of tile j: one 1-KiB LDS-DMA
+    // The ring is refilled in CHUNKS of CH k-steps, not in tiles: 144 KB of LDS then keep RING-2 = 10 chunks = 120 KB in flight
+    // per CU (tile-sized slots: 96 KB at best, and the scan ran at the memory latency, not at its bandwidth).  Chunk g of this
+    // workgroup = k-steps [CH*(g % NCH), +CH) of its tile g / NCH; NCH divides RING, so a tile's chunks are contiguous in the
+    // ring and the fragment reads may run ahead across chunk edges.  Past the workgroup's last tile the ring is refilled with
+    // chunks nobody reads, so that every chunk step issues the same PPC pieces and the counted wait is ONE constant.
+    auto src_of = [&](int g) {
+        const int jj = (g / NCH) < nmine ? (g / NCH) : nmine - 1;
+        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
+        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;      // wave-uniform: lives in scalar registers
+    };
+    auto dst_of = [&](int g) { return ring + ((size_t)(g % RING) * CH + wave * PPC) * 64; };
     auto issue_piece = [&](const u32x4 *src, u32x4 *dst, int p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
                                          (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
     };
-    // tile j of this workgroup, clamped to its last one: past the end the ring is refilled with a tile nobody reads, so that
-    // every iteration issues the same PPW pieces and the counted wait is ONE constant (no per-piece branches in the MFMA stream)
-    auto src_of = [&](int j) {
-        const int jj = j < nmine ? j : nmine - 1;
-        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
-        return xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
-    };
-    auto dst_of = [&](int j) { return ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64; };
-    auto issue = [&](int j) {
-        const u32x4 *src = src_of(j);
-        u32x4 *dst = dst_of(j);
+    if (nmine > 0) {
+        for (int g = 0; g < RING - 1; ++g) {
+            const u32x4 *src = src_of(g);
+            u32x4 *dst = dst_of(g);
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) issue_piece(src, dst, p);
-    };
-    if (nmine > 0)
-        for (int j = 0; j < SLOTS - 1; ++j) issue(j);
-
-    for (int j = 0; j < nmine; ++j) {
-        vm_wait<(SLOTS - 2) * PPW>();   // my pieces of tile j have landed; those of the SLOTS-2 tiles after it may be in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // tile j+SLOTS-1 goes into the slot tile j-1 was read from (free since the barrier).  A wave with one wave per SIMD has
-        // nobody to hide a burst of PPW DMA issues behind: the pieces are issued BETWEEN the MFMAs below, one every WAVES
-        // k-steps (all at once only by a wave that computes nothing)
-        const u32x4 *rsrc = src_of(j + SLOTS - 1);
-        u32x4 *rdst = dst_of(j + SLOTS - 1);
-        if (!act0) {
-            issue(j + SLOTS - 1);
-            continue;
+            for (int p = 0; p < PPC; ++p) issue_piece(src, dst, p);
         }
+    }
+
+    if (!act0) {   // a wave with no queries only moves data: the same waits, barriers and refills, nothing else
+        for (int g = 0; g < nmine * NCH; ++g) {
+            vm_wait<(RING - 3) * PPC>();
+            __builtin_amdgcn_s_barrier();
+            const u32x4 *rsrc = src_of(g + RING - 1);
+            u32x4 *rdst = dst_of(g + RING - 1);
+#pragma unroll
+            for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
+        }
+    }
+    for (int j = 0; act0 && j < nmine; ++j) {
         const int item = (int)blockIdx.x + j * (int)gridDim.x;
         const int64_t tile = (int64_t)item * tile_stride;
-        const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
-        const u32x4 *lp = ring + (size_t)(j % SLOTS) * KSTEPS * 64 + lane;
+        const u32x4 *lp = ring + (size_t)((j * NCH) % RING) * CH * 64 + lane;
         f32x16 a0 = {0}, a1 = {0};
-        u32x4 af[PF + 1];
+        // one straight-line body per case (both query blocks in use / only the first): a wave-uniform branch per k-step or per
+        // chunk cuts the schedule to pieces and costs registers at every join
+        auto tile_body = [&](auto both) {
+            u32x4 af[PF + 1];
 #pragma unroll
-        for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
-        if (act1) {   // (two straight-line bodies: a wave-uniform branch per k-step would cut the schedule into 48 pieces)
+            for (int c = 0; c < NCH; ++c) {
+                const int g = j * NCH + c;
+                // chunk g+1 has landed for everybody after this barrier (the reads below run up to PF k-steps into it), and
+                // everybody is done with chunk g-1, whose slot chunk g+RING-1 is refilled into
+                vm_wait<(RING - 3) * PPC>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const u32x4 *rsrc = src_of(g + RING - 1);
+                u32x4 *rdst = dst_of(g + RING - 1);
+                if (c == 0) {
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
-                const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q1[s]), a1, 0, 0, 0);
-                if (s % WAVES == 1) issue_piece(rsrc, rdst, s / WAVES);
-                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
+                    for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
+                }
+                // one wave per SIMD has nobody to hide DMA issues behind: the PPC pieces go BETWEEN the MFMAs, one every WAVES k-steps
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int s = c * CH + t;
+                    if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
+                    if constexpr (decltype(both)::value)
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q1[s]), a1, 0, 0, 0);
+                    if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
+                }
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s % (PF + 1)]), __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
-                if (s % WAVES == 1) issue_piece(rsrc, rdst, s / WAVES);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        };
+        if (act1)
+            tile_body(std::true_type{});
+        else
+            tile_body(std::false_type{});
+        const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
 
         if (MODE == 0) {
             float m0 = -INFINITY, m1 = -INFINITY;
