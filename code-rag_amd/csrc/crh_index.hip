@@ -27,8 +27,8 @@ namespace {
 
 constexpr int kWaves = 16;      // waves per scan workgroup (one workgroup per CU)
 constexpr int kRing = 8;        // 1-KiB loads in flight per wave
-constexpr int kWideWaves = 4;   // waves per k_scan_wide workgroup: each sees every tile of its workgroup for 64 queries, so the
-                                // workgroup's share of the candidate workspace is cut into 4 lists of 4 x wave_cap entries
+constexpr int kWideWaves = 8;   // waves per k_scan_wide workgroup: each sees every tile of its workgroup for 32 queries, so the
+                                // workgroup's share of the candidate workspace is cut into 8 lists of 2 x wave_cap entries
 constexpr int kStatusSlots = 1024;
 constexpr int64_t kWorkspaceBudget = 48LL << 30;
 
@@ -236,7 +236,7 @@ int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nit
 {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
 #define CRH_WIDE(KS)                                                                                                              \
-    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
+    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(512), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
                        h->gmax, kWideQ, h->wave_lists, kWideWaves, wave_cap * (kWaves / kWideWaves), stt->qcount, h->qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_WIDE(24); break;

@@ -497,187 +497,171 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
 
 // k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
-// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: a workgroup is 4 waves,
-// ONE per SIMD with the SIMD's whole 512-register file, and each wave keeps TWO 32-query blocks as MFMA B fragments in its
-// registers for the whole kernel (2 x KSTEPS x 4 = 384 registers at dim 768).  The CORPUS tiles go through LDS: a ring of
-// SLOTS tiles filled by LDS-DMA (global_load_lds_dwordx4, nt; every wave issues KSTEPS/4 of a tile's 1-KiB pieces), read
-// back by all 4 waves with one conflict-free ds_read_b128 per TWO MFMAs, PF reads ahead of the MFMAs that consume them (the
-// registers left over pay for that: with 8 waves of 256 registers and one read per MFMA the LDS latency was exposed and the
-// pass took 4.0 ms; profiles/r02_wide_scan.md).  One corpus pass serves 256 queries: HBM bytes per query / 4; per tile and
-// SIMD 96 MFMAs of 32x32x16 = 3072 cycles against ~4.9k cycles of HBM time per 48-KB tile per CU.
-// Per tile: ONE raw s_barrier -- each wave first waits (counted vmcnt) for its own pieces of tile j, so after the barrier
-// tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
-// issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's.
-// nblk = number of 32-query blocks in use: a wave whose blocks are both unused only moves data.
+// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: a workgroup is 8 waves
+// (two per SIMD, 256 registers each) and every wave keeps ONE 32-query block as MFMA B fragments in its registers for the
+// whole kernel (KSTEPS x 4 = 192 registers at dim 768).  The CORPUS goes through LDS: a ring of RING chunks of CH k-steps
+// filled by LDS-DMA (global_load_lds_dwordx4, nt; every wave issues CH/8 of a chunk's 1-KiB pieces) and read back by all 8
+// waves with one conflict-free ds_read_b128 per MFMA.  One corpus pass serves 256 queries: HBM bytes per query / 4.
+//
+// Three things measured on the way here (profiles/r02_wide_scan.md):
+//  * a chain of v_mfma_f32_32x32x16_bf16 on ONE accumulator runs at ~128 cycles per MFMA, not 32: the next MFMA waits for the
+//    previous result.  A SIMD needs FOUR independent accumulation chains to issue back to back -- here two waves per SIMD,
+//    each alternating two accumulators (even / odd k-steps, added once per tile).  With one chain per wave the pass took
+//    4.0 ms (8 waves) / 4.5 ms (4 waves holding two blocks each: 384 query registers leave no room for a second pair);
+//  * the ring is refilled in CHUNKS, not tiles: RING-2 chunks = 112 KB in flight per CU; the data path alone (waits,
+//    barriers, DMA, no arithmetic) streams 7.0 TB/s;
+//  * per chunk ONE raw s_barrier: each wave first waits (counted vmcnt) for its own pieces of chunk g+1, so after the barrier
+//    chunk g+1 has landed for everybody (the fragment reads run ahead into it) AND everybody is done with chunk g-1, whose
+//    slot chunk g+RING-1 is then issued into.  NCH divides RING, so a tile's chunks are contiguous in the ring.
+// Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's.  nblk = number of 32-query blocks
+// in use: a wave beyond it only moves data.  VAR 1 (debug build): the data path alone.
 template <int N>
 __device__ __forceinline__ void vm_wait()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(256) void k_scan_wide(
+#ifndef WIDE_PF
+#define WIDE_PF 2
+#endif
+#ifndef WIDE_QL
+#define WIDE_QL 5
+#endif
+template <int KSTEPS, int MODE, int VAR = 0>
+__global__ __launch_bounds__(512) void k_scan_wide(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
     const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax, int qstride,
     u32x4 *__restrict__ wave_lists, int lists_per_block, int wave_cap, unsigned int *__restrict__ qcount,
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
-    constexpr int WAVES = 4;
-    constexpr int CH = 12;                                 // k-steps (1-KiB pieces) per ring chunk
+    constexpr int WAVES = 8;
+    constexpr int CH = 8;                                  // k-steps (1-KiB pieces) per ring chunk: one piece per wave
     constexpr int NCH = KSTEPS / CH;                       // chunks per tile
-    constexpr int RING = 144 / CH;                         // 12 chunks = 144 KB of LDS = 3 tiles at dim 768, 6 at dim 384
     constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
-    constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
-    static_assert(KSTEPS % CH == 0 && RING % NCH == 0 && CH % WAVES == 0 && KSTEPS > PF, "ring geometry");
+    constexpr int PF = WIDE_PF;                            // corpus fragments read ahead of their MFMAs
+    constexpr int QL = KSTEPS == 48 ? WIDE_QL : 0;         // the wave's query fragments of the LAST QL k-steps live in LDS, not in
+                                                           // registers: 192 + 32 accumulators + fragments did not fit 256 registers
+    constexpr int QR = KSTEPS - QL;
+    constexpr int RING = 160 / CH - QL;                    // all 160 KB of LDS: QL KB of query fragments per wave, the rest is ring
+    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && KSTEPS > PF && (RING - 3) * PPC < 64 && RING >= 4, "ring geometry");
     __shared__ u32x4 ring[RING * CH * 64];
+    __shared__ u32x4 qlds[WAVES * (QL ? QL : 1) * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const bool act0 = 2 * wave < nblk, act1 = 2 * wave + 1 < nblk;
+    const bool active = wave < nblk;
 
-    u32x4 q0[KSTEPS], q1[KSTEPS];
+    u32x4 qreg[QR];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        q0[s] = act0 ? qfrag[((size_t)(2 * wave) * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-        q1[s] = act1 ? qfrag[((size_t)(2 * wave + 1) * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-    }
-    float t0 = 0.f, t1 = 0.f;
-    if (MODE == 1) {
-        t0 = act0 ? tau[wave * 64 + (lane & 31)] : INFINITY;
-        t1 = act1 ? tau[wave * 64 + 32 + (lane & 31)] : INFINITY;
-    }
+    for (int s = 0; s < QR; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int s = 0; s < QL; ++s) qlds[(wave * QL + s) * 64 + lane] = active ? qfrag[((size_t)wave * KSTEPS + QR + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    const u32x4 *qlp = qlds + (size_t)wave * QL * 64 + lane;      // (only this wave reads what it wrote: no barrier needed)
+    float t0 = 0.f;
+    if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
 
     const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
     unsigned int wcnt = 0;
 
-    // The ring is refilled in CHUNKS of CH k-steps, not in tiles: 144 KB of LDS then keep RING-2 = 10 chunks = 120 KB in flight
-    // per CU (tile-sized slots: 96 KB at best, and the scan ran at the memory latency, not at its bandwidth).  Chunk g of this
-    // workgroup = k-steps [CH*(g % NCH), +CH) of its tile g / NCH; NCH divides RING, so a tile's chunks are contiguous in the
-    // ring and the fragment reads may run ahead across chunk edges.  Past the workgroup's last tile the ring is refilled with
-    // chunks nobody reads, so that every chunk step issues the same PPC pieces and the counted wait is ONE constant.
+    // chunk g of this workgroup = k-steps [CH*(g % NCH), +CH) of its tile g / NCH, clamped to the last tile: past the end the
+    // ring is refilled with chunks nobody reads, so that every chunk step issues the same PPC pieces and the counted wait is ONE
+    // constant.  The source base is wave-uniform (scalar registers); the lane offset is added by the instruction.
     auto src_of = [&](int g) {
         const int jj = (g / NCH) < nmine ? (g / NCH) : nmine - 1;
         const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
-        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;      // wave-uniform: lives in scalar registers
+        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;
     };
-    auto dst_of = [&](int g) { return ring + ((size_t)(g % RING) * CH + wave * PPC) * 64; };
-    auto issue_piece = [&](const u32x4 *src, u32x4 *dst, int p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
-                                         (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
-    };
-    if (nmine > 0) {
-        for (int g = 0; g < RING - 1; ++g) {
-            const u32x4 *src = src_of(g);
-            u32x4 *dst = dst_of(g);
+    auto issue = [&](int g) {
+        const u32x4 *src = src_of(g);
+        u32x4 *dst = ring + ((size_t)(g % RING) * CH + wave * PPC) * 64;
 #pragma unroll
-            for (int p = 0; p < PPC; ++p) issue_piece(src, dst, p);
-        }
-    }
+        for (int p = 0; p < PPC; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
+    };
+    if (nmine > 0)
+        for (int g = 0; g < RING - 1; ++g) issue(g);
 
-    if (!act0) {   // a wave with no queries only moves data: the same waits, barriers and refills, nothing else
+    if (!active || VAR == 1) {   // a wave with no queries only moves data: the same waits, barriers and refills, nothing else
         for (int g = 0; g < nmine * NCH; ++g) {
             vm_wait<(RING - 3) * PPC>();
             __builtin_amdgcn_s_barrier();
-            const u32x4 *rsrc = src_of(g + RING - 1);
-            u32x4 *rdst = dst_of(g + RING - 1);
-#pragma unroll
-            for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
+            issue(g + RING - 1);
         }
     }
-    for (int j = 0; act0 && j < nmine; ++j) {
+    for (int j = 0; active && VAR != 1 && j < nmine; ++j) {
         const int item = (int)blockIdx.x + j * (int)gridDim.x;
         const int64_t tile = (int64_t)item * tile_stride;
-        const u32x4 *lp = ring + (size_t)((j * NCH) % RING) * CH * 64 + lane;
-        f32x16 a0 = {0}, a1 = {0};
-        // one straight-line body per case (both query blocks in use / only the first): a wave-uniform branch per k-step or per
-        // chunk cuts the schedule to pieces and costs registers at every join
-        auto tile_body = [&](auto both) {
-            u32x4 af[PF + 1];
+        // LDS address of k-step s of this tile: its chunk (j*NCH + s/CH) sits at slot (.. % RING); a tile's chunks need not be
+        // contiguous in the ring, so the address is rebuilt per read from a scalar slot offset and the lane's own 16 bytes
+        auto frag = [&](int s) { return ring[(size_t)((j * NCH + s / CH) % RING) * CH * 64 + (s % CH) * 64 + lane]; };
+        f32x16 a0 = {0}, b0 = {0};      // even / odd k-steps: two independent MFMA chains per wave, four per SIMD
+        u32x4 af[PF + 1], ql[2];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int g = j * NCH + c;
-                // chunk g+1 has landed for everybody after this barrier (the reads below run up to PF k-steps into it), and
-                // everybody is done with chunk g-1, whose slot chunk g+RING-1 is refilled into
-                vm_wait<(RING - 3) * PPC>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const u32x4 *rsrc = src_of(g + RING - 1);
-                u32x4 *rdst = dst_of(g + RING - 1);
-                if (c == 0) {
+        for (int c = 0; c < NCH; ++c) {
+            vm_wait<(RING - 3) * PPC>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(j * NCH + c + RING - 1);   // (the SIMD's other wave computes meanwhile)
+            if (c == 0) {
 #pragma unroll
-                    for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
-                }
-                // one wave per SIMD has nobody to hide DMA issues behind: the PPC pieces go BETWEEN the MFMAs, one every WAVES k-steps
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const int s = c * CH + t;
-                    if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
-                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q0[s]), a0, 0, 0, 0);
-                    if constexpr (decltype(both)::value)
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, q1[s]), a1, 0, 0, 0);
-                    if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);
-                    __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
-                }
+                for (int s = 0; s < PF; ++s) af[s] = frag(s);
             }
-        };
-        if (act1)
-            tile_body(std::true_type{});
-        else
-            tile_body(std::false_type{});
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int s = c * CH + t;
+                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = frag(s + PF);
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
+                if (QL && s + 1 >= QR && s + 1 < KSTEPS) ql[(s + 1) & 1] = qlp[(s + 1 - QR) * 64];
+                const bf16x8 qb = __builtin_bit_cast(bf16x8, s < QR ? qreg[s < QR ? s : 0] : ql[s & 1]);
+                if (s & 1)
+                    b0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, b0, 0, 0, 0);
+                else
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, a0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] += b0[r];
         const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
 
         if (MODE == 0) {
-            float m0 = -INFINITY, m1 = -INFINITY;
+            float m0 = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool ok = (vmask >> row) & 1u;
-                m0 = fmaxf(m0, ok ? a0[r] : -INFINITY);
-                m1 = fmaxf(m1, ok ? a1[r] : -INFINITY);
+                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? a0[r] : -INFINITY);
             }
             m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            m1 = fmaxf(m1, __shfl_xor(m1, 32));
-            if (h == 0) {
-                gmax[(size_t)item * qstride + wave * 64 + lane] = m0;
-                if (act1) gmax[(size_t)item * qstride + wave * 64 + 32 + lane] = m1;
-            }
+            if (h == 0) gmax[(size_t)item * qstride + wave * 32 + lane] = m0;
         } else {
-            float m0 = a0[0], m1 = a1[0];
+            float m0 = a0[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                m0 = fmaxf(m0, a0[r]);
-                m1 = fmaxf(m1, a1[r]);
-            }
-            const bool any = (m0 >= t0) || (m1 >= t1);
-            if (__ballot(any) != 0ull && vmask != 0u) {
+            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, a0[r]);
+            if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
                 uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
                 asm volatile("" : "+v"(rowbase));   // keep the 16 row numbers out of the loop-invariant registers (rare path)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const float tq = qb ? t1 : t0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);
-                        const int rbit = row + 4 * h;
-                        const float sc = qb ? a1[r] : a0[r];
-                        const bool pass = ((vmask >> rbit) & 1u) && (sc >= tq);
-                        const unsigned long long pm = __ballot(pass);
-                        if (pm != 0ull) {
-                            const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-                            const unsigned int pos = wcnt + pre;
-                            if (pass && pos < (unsigned int)wave_cap) {
-                                u32x4 e;
-                                e.x = f32_bits(sc);
-                                e.y = rowbase + row;
-                                e.z = (uint32_t)(wave * 64 + qb * 32 + (lane & 31));
-                                e.w = 0u;
-                                mylist[pos] = e;
-                            }
-                            wcnt += (unsigned int)__popcll(pm);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    const int rbit = row + 4 * h;
+                    const float sc = a0[r];
+                    const bool pass = ((vmask >> rbit) & 1u) && (sc >= t0);
+                    const unsigned long long pm = __ballot(pass);
+                    if (pm != 0ull) {
+                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                        const unsigned int pos = wcnt + pre;
+                        if (pass && pos < (unsigned int)wave_cap) {
+                            u32x4 e;
+                            e.x = f32_bits(sc);
+                            e.y = rowbase + row;
+                            e.z = (uint32_t)(wave * 32 + (lane & 31));
+                            e.w = 0u;
+                            mylist[pos] = e;
                         }
+                        wcnt += (unsigned int)__popcll(pm);
                     }
                 }
             }
@@ -697,8 +681,10 @@ __global__ __launch_bounds__(256) void k_scan_wide(
             atomicMax(&status->max_wave_cnt, wcnt);
             if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
         }
-        hist[tid] = 0u;      // 256 threads, 256 bins
-        off[tid] = 0u;
+        if (tid < kWideQ) {
+            hist[tid] = 0u;
+            off[tid] = 0u;
+        }
         __syncthreads();
         const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
         for (int w = 0; w < WAVES; ++w) {
@@ -706,7 +692,7 @@ __global__ __launch_bounds__(256) void k_scan_wide(
             for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & (kWideQ - 1)], 1u);
         }
         __syncthreads();
-        base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
+        if (tid < kWideQ) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
         __syncthreads();
         for (int w = 0; w < WAVES; ++w) {
             const unsigned int n = wc[w];
