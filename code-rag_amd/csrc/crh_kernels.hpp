@@ -497,37 +497,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
 
 // k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
-// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: a workgroup is 8 waves
-// (two per SIMD, 256 registers each) and every wave keeps ONE 32-query block as MFMA B fragments in its registers for the
-// whole kernel (KSTEPS x 4 = 192 registers at dim 768).  The CORPUS goes through LDS: a ring of RING chunks of CH k-steps
-// filled by LDS-DMA (global_load_lds_dwordx4, nt; every wave issues CH/8 of a chunk's 1-KiB pieces) and read back by all 8
-// waves with one conflict-free ds_read_b128 per MFMA.  One corpus pass serves 256 queries: HBM bytes per query / 4.
-//
-// Three things measured on the way here (profiles/r02_wide_scan.md):
-//  * a chain of v_mfma_f32_32x32x16_bf16 on ONE accumulator runs at ~128 cycles per MFMA, not 32: the next MFMA waits for the
-//    previous result.  A SIMD needs FOUR independent accumulation chains to issue back to back -- here two waves per SIMD,
-//    each alternating two accumulators (even / odd k-steps, added once per tile).  With one chain per wave the pass took
-//    4.0 ms (8 waves) / 4.5 ms (4 waves holding two blocks each: 384 query registers leave no room for a second pair);
-//  * the ring is refilled in CHUNKS, not tiles: RING-2 chunks = 112 KB in flight per CU; the data path alone (waits,
-//    barriers, DMA, no arithmetic) streams 7.0 TB/s;
-//  * per chunk ONE raw s_barrier: each wave first waits (counted vmcnt) for its own pieces of chunk g+1, so after the barrier
-//    chunk g+1 has landed for everybody (the fragment reads run ahead into it) AND everybody is done with chunk g-1, whose
-//    slot chunk g+RING-1 is then issued into.  NCH divides RING, so a tile's chunks are contiguous in the ring.
-// Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's.  nblk = number of 32-query blocks
-// in use: a wave beyond it only moves data.  VAR 1 (debug build): the data path alone.
+// and a call with more queries pays one corpus pass per 64.  k_scan_wide turns the operands around: each of a workgroup's
+// 8 waves keeps ONE 32-query block as MFMA B fragments in its own registers for the whole kernel (KSTEPS x 4 VGPRs: 192 at
+// dim 768 -- two waves per SIMD at 256 registers each), and the CORPUS tiles go through LDS: a ring of SLOTS tiles filled by
+// LDS-DMA (global_load_lds_dwordx4, nt; every wave issues KSTEPS/8 of a tile's 1-KiB pieces), read back by all 8 waves with
+// one conflict-free ds_read_b128 per MFMA.  One corpus pass then serves 256 queries: HBM bytes per query / 4.  The pass is
+// MFMA-bound, not HBM-bound: 3.9 TFLOP per 10M rows run at ~0.96 PFLOP/s (4.0 ms; the ring's data path alone, with the waits
+// and barriers but no arithmetic, streams 7.0 TB/s = 2.2 ms).  Variants measured and dropped (profiles/r02_wide_scan.md): 4
+// waves holding two blocks each with a 6-deep LDS read-ahead (4.5 ms: one wave per SIMD leaves nobody to hide the DMA issue
+// and the epilogue behind), the ring refilled in 8/12-KB chunks (112-120 KB in flight instead of 96: no gain once MFMA-bound),
+// two accumulation chains per wave with the last query k-steps parked in LDS to make room (4.1 ms).
+// Per tile: ONE raw s_barrier -- each wave first waits (counted vmcnt) for its own pieces of tile j, so after the barrier
+// tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
+// issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's (one 32-query
+// block per wave instead of two).  nblk = number of 32-query blocks in use: waves beyond it only move data.
 template <int N>
 __device__ __forceinline__ void vm_wait()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-#ifndef WIDE_PF
-#define WIDE_PF 2
-#endif
-#ifndef WIDE_QL
-#define WIDE_QL 5
-#endif
-template <int KSTEPS, int MODE, int VAR = 0>
+template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(512) void k_scan_wide(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
     const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax, int qstride,
@@ -535,29 +525,19 @@ __global__ __launch_bounds__(512) void k_scan_wide(
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
     constexpr int WAVES = 8;
-    constexpr int CH = 8;                                  // k-steps (1-KiB pieces) per ring chunk: one piece per wave
-    constexpr int NCH = KSTEPS / CH;                       // chunks per tile
-    constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
-    constexpr int PF = WIDE_PF;                            // corpus fragments read ahead of their MFMAs
-    constexpr int QL = KSTEPS == 48 ? WIDE_QL : 0;         // the wave's query fragments of the LAST QL k-steps live in LDS, not in
-                                                           // registers: 192 + 32 accumulators + fragments did not fit 256 registers
-    constexpr int QR = KSTEPS - QL;
-    constexpr int RING = 160 / CH - QL;                    // all 160 KB of LDS: QL KB of query fragments per wave, the rest is ring
-    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && KSTEPS > PF && (RING - 3) * PPC < 64 && RING >= 4, "ring geometry");
-    __shared__ u32x4 ring[RING * CH * 64];
-    __shared__ u32x4 qlds[WAVES * (QL ? QL : 1) * 64];
+    constexpr int PPW = KSTEPS / WAVES;                   // 1-KiB pieces of a tile issued by each wave
+    constexpr int SLOTS = (KSTEPS * 3 <= 144) ? 3 + (144 - KSTEPS * 3) / KSTEPS : 3;   // 144 KB of LDS: 3 tiles at dim 768, 6 at 384
+    static_assert(KSTEPS % WAVES == 0 && SLOTS >= 3 && SLOTS * KSTEPS <= 144, "ring geometry");
+    __shared__ u32x4 ring[SLOTS * KSTEPS * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const bool active = wave < nblk;
 
-    u32x4 qreg[QR];
+    u32x4 qreg[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < QR; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int s = 0; s < QL; ++s) qlds[(wave * QL + s) * 64 + lane] = active ? qfrag[((size_t)wave * KSTEPS + QR + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-    const u32x4 *qlp = qlds + (size_t)wave * QL * 64 + lane;      // (only this wave reads what it wrote: no barrier needed)
+    for (int s = 0; s < KSTEPS; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
     float t0 = 0.f;
     if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
 
@@ -565,67 +545,46 @@ __global__ __launch_bounds__(512) void k_scan_wide(
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
     unsigned int wcnt = 0;
 
-    // chunk g of this workgroup = k-steps [CH*(g % NCH), +CH) of its tile g / NCH, clamped to the last tile: past the end the
-    // ring is refilled with chunks nobody reads, so that every chunk step issues the same PPC pieces and the counted wait is ONE
-    // constant.  The source base is wave-uniform (scalar registers); the lane offset is added by the instruction.
-    auto src_of = [&](int g) {
-        const int jj = (g / NCH) < nmine ? (g / NCH) : nmine - 1;
-        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
-        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;
-    };
-    auto issue = [&](int g) {
-        const u32x4 *src = src_of(g);
-        u32x4 *dst = ring + ((size_t)(g % RING) * CH + wave * PPC) * 64;
+    auto issue = [&](int j) {
+        const int64_t tile = (int64_t)((int)blockIdx.x + j * (int)gridDim.x) * tile_stride;
+        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
+        u32x4 *dst = ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64;
 #pragma unroll
-        for (int p = 0; p < PPC; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+        for (int p = 0; p < PPW; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
                                              (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
     };
-    if (nmine > 0)
-        for (int g = 0; g < RING - 1; ++g) issue(g);
+    for (int j = 0; j < SLOTS - 1 && j < nmine; ++j) issue(j);
 
-    if (!active || VAR == 1) {   // a wave with no queries only moves data: the same waits, barriers and refills, nothing else
-        for (int g = 0; g < nmine * NCH; ++g) {
-            vm_wait<(RING - 3) * PPC>();
-            __builtin_amdgcn_s_barrier();
-            issue(g + RING - 1);
-        }
-    }
-    for (int j = 0; active && VAR != 1 && j < nmine; ++j) {
+    for (int j = 0; j < nmine; ++j) {
+        // my pieces of tile j have landed once at most min(SLOTS-2, tiles after j) later tiles of mine are still in flight
+        const int ahead = (nmine - 1 - j) < (SLOTS - 2) ? (nmine - 1 - j) : (SLOTS - 2);
+        if (ahead >= 4) vm_wait<4 * PPW>();
+        else if (ahead == 3) vm_wait<3 * PPW>();
+        else if (ahead == 2) vm_wait<2 * PPW>();
+        else if (ahead == 1) vm_wait<PPW>();
+        else vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + SLOTS - 1 < nmine) issue(j + SLOTS - 1);   // into the slot tile j-1 was read from: free since the barrier
+
+        if (!active) continue;
         const int item = (int)blockIdx.x + j * (int)gridDim.x;
         const int64_t tile = (int64_t)item * tile_stride;
-        // LDS address of k-step s of this tile: its chunk (j*NCH + s/CH) sits at slot (.. % RING); a tile's chunks need not be
-        // contiguous in the ring, so the address is rebuilt per read from a scalar slot offset and the lane's own 16 bytes
-        auto frag = [&](int s) { return ring[(size_t)((j * NCH + s / CH) % RING) * CH * 64 + (s % CH) * 64 + lane]; };
-        f32x16 a0 = {0}, b0 = {0};      // even / odd k-steps: two independent MFMA chains per wave, four per SIMD
-        u32x4 af[PF + 1], ql[2];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            vm_wait<(RING - 3) * PPC>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue(j * NCH + c + RING - 1);   // (the SIMD's other wave computes meanwhile)
-            if (c == 0) {
-#pragma unroll
-                for (int s = 0; s < PF; ++s) af[s] = frag(s);
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int s = c * CH + t;
-                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = frag(s + PF);
-                const bf16x8 xa = __builtin_bit_cast(bf16x8, af[s % (PF + 1)]);
-                if (QL && s + 1 >= QR && s + 1 < KSTEPS) ql[(s + 1) & 1] = qlp[(s + 1 - QR) * 64];
-                const bf16x8 qb = __builtin_bit_cast(bf16x8, s < QR ? qreg[s < QR ? s : 0] : ql[s & 1]);
-                if (s & 1)
-                    b0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, b0, 0, 0, 0);
-                else
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, a0, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a0[r] += b0[r];
         const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
+        const u32x4 *lp = ring + (size_t)(j % SLOTS) * KSTEPS * 64 + lane;
+        // 192 of the wave's 256 registers hold its queries: the corpus fragments get a 4-deep rotation (three ds_read_b128 in
+        // flight ahead of the MFMA that consumes the fourth), enough to cover the LDS latency behind 32-cycle MFMAs
+        f32x16 a0 = {0};
+        u32x4 af[4];
+        af[0] = lp[0];
+        af[1] = lp[64];
+        af[2] = lp[128];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + 3 < KSTEPS) af[(s + 3) & 3] = lp[(s + 3) * 64];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s & 3]), __builtin_bit_cast(bf16x8, qreg[s]), a0, 0, 0, 0);
+        }
 
         if (MODE == 0) {
             float m0 = -INFINITY;
