@@ -36,7 +36,7 @@ _T0 = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-ALL_LEGS = ("filtered", "config5", "f32_store", "embed", "embed_e2e", "c1", "cpu")
+ALL_LEGS = ("filtered", "wide", "config5", "f32_store", "embed", "embed_e2e", "c1", "cpu")
 
 
 def log(msg: str) -> None:
@@ -96,6 +96,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="time box of each CPU baseline leg")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL (the measurement); gloo = launcher rehearsal without device work")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="with --backend gloo on a box with ONE GPU: every rank uses device 0 and the real N>1 path runs with "
+                         "host-staged gloo collectives (rehearsal of everything but RCCL; not a measurement)")
     return ap.parse_args()
 
 
@@ -110,10 +113,39 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.backend == "gloo":
+    if args.backend == "gloo" and not args.share_gpu:
         rehearse(args, json_fd)
     else:
         run(args, json_fd)
+
+
+class HostStagedCollectives:
+    """`torch.distributed` for device tensors over gloo (collectives staged through host memory): what `--backend gloo
+    --share-gpu` uses to run the REAL N>1 path -- shard scans, merge kernel, side-column completion -- with several ranks on
+    ONE GPU, where RCCL refuses to put two ranks on a device.  A rehearsal of everything but RCCL itself, not a measurement."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def all_gather_into_tensor(self, out, inp):
+        o, i = out.cpu(), inp.cpu()
+        self._d.all_gather_into_tensor(o, i)
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op or self._d.ReduceOp.SUM)
+        t.copy_(h)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------ rehearsal (no GPU)
@@ -261,7 +293,7 @@ def run(args, json_fd) -> None:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -275,7 +307,11 @@ def run(args, json_fd) -> None:
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = HostStagedCollectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     legs = set(ALL_LEGS if world == 1 else ("config5", "embed")) if args.legs is None else \
         set(x for x in args.legs.split(",") if x and x != "none")
     unknown = legs - set(ALL_LEGS)
@@ -284,7 +320,7 @@ def run(args, json_fd) -> None:
     if args.no_cpu_baseline or world > 1:
         legs -= {"cpu"}
     if world > 1:
-        legs -= {"c1", "embed_e2e", "f32_store", "filtered"}      # one-GPU verification legs
+        legs -= {"c1", "embed_e2e", "f32_store", "filtered", "wide"}      # one-GPU verification legs
 
     D, N, B, K = 768, args.rows, args.queries, args.k
     if args.scaling == "strong":
@@ -411,12 +447,15 @@ def run(args, json_fd) -> None:
         "roofline": roof,
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
-        "rccl_ranks": rccl_ranks,
+        "rccl_ranks": rccl_ranks if args.backend == "nccl" else None,
+        "collective_ranks": rccl_ranks, "backend": args.backend if dist is not None else None,
         "exchange_ms_device": (dict(pct(exchange), what="1 RCCL all-gather of the [scores | rows] records + k_merge_topk, rank 0")
                                if exchange is not None else None),
         "search_stats": stats,
         "parity": parity,
     }
+    if args.backend == "gloo":
+        out["rehearsal"] = "ranks share one GPU and the collectives are host-staged gloo: everything but RCCL itself; NOT a measurement"
     log("parity subsample checked" if parity else "parity subsample skipped")
 
     def leg(name, fn, *a):
@@ -443,7 +482,40 @@ def run(args, json_fd) -> None:
         log(f"filtered: {r['ms_per_step']:.3f} ms/step")
         return res
 
+    def wide_leg():
+        """One search call with 512 queries: two passes of k_scan_wide (256 queries share a corpus pass, query fragments in
+        registers, corpus tiles through an LDS-DMA ring) instead of eight 64-query passes.  MFMA-bound, not HBM-bound."""
+        nq = 512
+        q512 = np.random.default_rng(11).standard_normal((nq, D)).astype(np.float32)
+        q512[:B] = qs
+        qd512 = torch.from_numpy(q512).to(dev)
+        r = timed_search(torch, idx, qd512, K, None, max(5, args.sub_steps // 2), 2, stream)
+        flops = 2.0 * 256 * N * D
+        ach = flops / (r["scan_ms"] * 1e-3) / 1e12 if r["scan_ms"] > 0 else 0.0
+        same = bool(torch.equal(r["rows"][:B], headline_rows - row_base))
+        # one 64-query slice of the batch searched on its own: the same rows, the same score bits
+        s64 = torch.empty((64, K), dtype=torch.float32, device=dev)
+        r64 = torch.empty((64, K), dtype=torch.int64, device=dev)
+        idx.search(qd512[320:384], K, out_scores=s64, out_rows=r64, stream=stream)
+        idx.search_finish(stream)
+        torch.cuda.synchronize()
+        same = same and bool(torch.equal(r64, r["rows"][320:384]) and torch.equal(s64.view(torch.int32), r["scores"][320:384].view(torch.int32)))
+        res = {"workload": f"{N}x{D} {args.dtype}, ONE search call with {nq} queries, exact top-{K}", "value": nq / (r["ms_per_step"] * 1e-3) * (N / 1e7),
+               "unit": out["unit"], "ms_per_step": r["ms_per_step"], "steps": max(5, args.sub_steps // 2), "step_ms_device": r["step_ms_device"],
+               "passes_per_call": r["scan_launches"] / max(5, args.sub_steps // 2),
+               "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                            "kernel": "k_scan_wide<48,1>", "kernel_ms": r["scan_ms"], "launches": r["scan_launches"], "algorithmic_flops_per_launch": flops,
+                            "hbm_GBps": float(N) * D * 2 / (r["scan_ms"] * 1e-3) / 1e9, "traffic": None},
+               "search_stats": r["stats"],
+               "parity": {"identical_to_64_query_passes": same, "what": "rows and f32 score bits of queries 0..63 (the headline batch) and 320..383"}}
+        if orc is not None:
+            m = min(50_000, head.shape[0])
+            res["parity"].update(subsample_parity(np, ffi, orc, head[:m], head_codes[:m] if head_codes is not None else None, q512, K, dtype, local_rank))
+        log(f"wide: {r['ms_per_step']:.3f} ms per 512-query call")
+        return res
+
     leg("filtered", filtered_leg)
+    leg("wide", wide_leg)
     leg("config5", config5_leg, np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, args.sub_steps, stream)
     idx.close()
     del idx
