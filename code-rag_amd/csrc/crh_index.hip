@@ -47,6 +47,7 @@ struct Pending {
 struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
+    bool use_ring = true;  // <= 64 queries: k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs) instead of k_scan
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
@@ -229,6 +230,28 @@ int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, 
     return CRH_OK;
 }
 
+// the ring scan (<= 64 queries): 4 waves per workgroup, each sees every tile of its workgroup for its block's 16 rows
+constexpr int kRingWaves = 4;
+template <int MODE>
+int launch_scan_ring(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
+                     SearchStatus *stt)
+{
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
+#define CRH_RING(KS)                                                                                                               \
+    hipLaunchKernelGGL((k_scan_ring<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
+                       h->gmax, h->wave_lists, kRingWaves, wave_cap * (kWaves / kRingWaves), stt->qcount, h->qlist, qcap, stt)
+    switch (h->ksteps) {
+    case 24: CRH_RING(24); break;
+    case 48: CRH_RING(48); break;
+    case 64: CRH_RING(64); break;
+    case 96: CRH_RING(96); break;
+    default: return fail(CRH_E_INTERNAL, "no ring scan kernel for %d k-steps", h->ksteps);
+    }
+#undef CRH_RING
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 // the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
 template <int MODE>
 int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
@@ -277,15 +300,21 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
+    const bool ring = !wide && h->use_ring;
     if (wide)
         CRH_TRY(launch_scan_wide<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
+    else if (ring)
+        CRH_TRY(launch_scan_ring<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else
         CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
-    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau, qstride);
+    const int GS = ring ? 2 * G : G;     // the ring scan seeds with one maximum per HALF tile
+    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)GS * 4, st, h->gmax, GS, k, margin, nq, h->tau, qstride);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
     if (wide)
         CRH_TRY(launch_scan_wide<1>(h, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
+    else if (ring)
+        CRH_TRY(launch_scan_ring<1>(h, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
     else
         CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
@@ -402,7 +431,11 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     crh_index *h = new crh_index();
     h->dim = dim;
     h->ksteps = dim / 16;
-    h->batch_q = dim > 1024 ? 32 : 64;
+    {   // CODERAG_HIP_SCAN=stream selects k_scan (corpus straight into registers) for the <= 64-query passes: A/B timing only
+        const char *e = getenv("CODERAG_HIP_SCAN");
+        h->use_ring = !(e && strcmp(e, "stream") == 0);
+    }
+    h->batch_q = (dim > 1024 && !h->use_ring) ? 32 : 64;   // (k_scan's 64-query image does not fit LDS at dim 1536)
     h->wide_ok = dim <= 768 && getenv("CODERAG_HIP_NO_WIDE_SCAN") == nullptr;   // (the env switch exists for A/B timing only)
     h->dtype = dtype;
     h->ncols = n_code_cols;

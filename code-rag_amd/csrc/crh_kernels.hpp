@@ -25,6 +25,7 @@ namespace crh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -494,6 +495,236 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     }
 }
 
+// ------------------------------------------------------------------ the ring scan (<= 64 queries, corpus through LDS)
+
+// k_scan streams every corpus tile straight into MFMA operand registers; its loads alone reach 6.97 TB/s and the scan 96-97 %
+// of that.  The LDS-DMA ring built for k_scan_wide moves data faster still (7.0 TB/s with all its waits and barriers), but a
+// wave that holds a whole 32-query block runs one dependent MFMA chain of KSTEPS links per tile (~120 cycles per link), which
+// is slower than the data.  k_scan_ring splits K instead: 4 waves = 2 query blocks x 2 K-halves, ONE wave per SIMD; a wave
+// keeps its block's fragments of its K-half in registers (KSTEPS/2 x 4), accumulates its chunks of a tile on FOUR alternating
+// accumulators (independent chains), folds them, and swaps half of the 16 partial-sum registers with its partner through
+// 8 KB of LDS: wave (block b, half 0) ends up with the complete scores of accumulator registers 0-7 (rows 0-3, 8-11 [+4 for
+// the upper lanes]), wave (b, 1) with registers 8-15, and each thresholds / nominates its own 16 rows.  The exchange rides on
+// the ring's barriers: a tile's reduction and epilogue run right after the first barrier of the NEXT tile.
+// Ring: chunks of CH k-steps (12 KB at dim 768), RING chunks = 144 KB, RING-2 in flight; one raw s_barrier per chunk: each
+// wave first waits (counted vmcnt) for its own pieces of chunk g, so after the barrier chunk g has landed for everybody and
+// everybody is done with chunk g-1, whose slot chunk g+RING-1 is then issued into (computing waves issue their pieces
+// between their MFMAs, the others in a burst).  Past the workgroup's last tile the ring is refilled with chunks nobody reads,
+// so that the counted wait is ONE constant.  ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc drain
+// vmcnt before every LDS read).
+// Seed (MODE 0) writes one maximum per HALF tile (the 16 rows a wave owns): gmax[(2*item + half)*64 + query]; the k-th largest
+// of those is a lower bound of the k-th score just as with whole tiles (k half-tiles hold k distinct rows).
+template <int N>
+__device__ __forceinline__ void vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(256) void k_scan_ring(
+    const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
+    const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax,
+    u32x4 *__restrict__ wave_lists, int lists_per_block, int wave_cap, unsigned int *__restrict__ qcount,
+    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
+{
+    constexpr int WAVES = 4;
+    constexpr int KH = KSTEPS / 2;                         // k-steps of a K-half
+    constexpr int CH = (KH % 16 == 0) ? 16 : 12;           // k-steps (1-KiB pieces) per ring chunk
+    constexpr int NCH = KSTEPS / CH, CPH = KH / CH;        // chunks per tile / per K-half
+    constexpr int RING = 144 / CH;                         // 144 KB of ring
+    constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
+    constexpr int PF = 4;                                  // corpus fragments read ahead of their MFMAs
+    static_assert(KH % CH == 0 && CH % WAVES == 0 && CH > PF && (RING - 2) * PPC < 64 && RING >= 4, "ring geometry");
+    __shared__ u32x4 lds[(RING * CH + 2 * WAVES) * 64];    // the ring, then 2 KB per wave for the partial-sum exchange
+    u32x4 *ring = lds;
+    u32x4 *xch = lds + RING * CH * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lh = lane >> 5;
+    const int blk = wave & 1, half = wave >> 1;
+    const bool active = blk < nblk;
+
+    u32x4 qreg[KH];
+#pragma unroll
+    for (int s = 0; s < KH; ++s) qreg[s] = active ? qfrag[((size_t)blk * KSTEPS + half * KH + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    float t0 = 0.f;
+    if (MODE == 1) t0 = active ? tau[blk * 32 + (lane & 31)] : INFINITY;
+
+    const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
+    unsigned int wcnt = 0;
+
+    auto src_of = [&](int g) {          // chunk g of this workgroup, clamped to its last tile; wave-uniform (scalar registers)
+        const int jj = (g / NCH) < nmine ? (g / NCH) : nmine - 1;
+        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
+        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;
+    };
+    auto dst_of = [&](int g) { return ring + ((size_t)(g % RING) * CH + wave * PPC) * 64; };
+    auto issue_piece = [&](const u32x4 *src, u32x4 *dst, int p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
+    };
+    if (nmine > 0) {
+        for (int g = 0; g < RING - 1; ++g) {
+            const u32x4 *src = src_of(g);
+            u32x4 *dst = dst_of(g);
+#pragma unroll
+            for (int p = 0; p < PPC; ++p) issue_piece(src, dst, p);
+        }
+    }
+
+    f32x16 part = {0};                  // this wave's partial scores of the tile just finished (its K-half)
+    // complete the 8 accumulator registers this wave owns with the partner's partial sums and nominate / take the maximum
+    auto finish_tile = [&](int item, uint32_t vmask) {
+        const int64_t tile = (int64_t)item * tile_stride;
+        const u32x4 *px = xch + (size_t)(blk + 2 * (1 - half)) * 2 * 64 + lane;     // what the partner wave left for me
+        const f32x4 p0 = __builtin_bit_cast(f32x4, px[0]), p1 = __builtin_bit_cast(f32x4, px[64]);
+        float sc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float mine = half ? part[8 + i] : part[i], theirs = i < 4 ? p0[i] : p1[i - 4];   // (selects, not indexed registers)
+            sc[i] = half ? theirs + mine : mine + theirs;          // always (K-half 0) + (K-half 1): the two waves agree
+        }
+        if (MODE == 0) {
+            float m0 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = half * 8 + i;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? sc[i] : -INFINITY);
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            if (lh == 0) gmax[((size_t)item * 2 + half) * 64 + blk * 32 + lane] = m0;
+        } else {
+            float m0 = sc[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m0 = fmaxf(m0, sc[i]);
+            if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
+                uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)lh;
+                asm volatile("" : "+v"(rowbase));   // keep the row numbers out of the loop-invariant registers (rare path)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = half * 8 + i;
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    const int rbit = row + 4 * lh;
+                    const bool pass = ((vmask >> rbit) & 1u) && (sc[i] >= t0);
+                    const unsigned long long pm = __ballot(pass);
+                    if (pm != 0ull) {
+                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                        const unsigned int pos = wcnt + pre;
+                        if (pass && pos < (unsigned int)wave_cap) {
+                            u32x4 e;
+                            e.x = f32_bits(sc[i]);
+                            e.y = rowbase + row;
+                            e.z = (uint32_t)(blk * 32 + (lane & 31));
+                            e.w = 0u;
+                            mylist[pos] = e;
+                        }
+                        wcnt += (unsigned int)__popcll(pm);
+                    }
+                }
+            }
+        }
+    };
+
+    int prev_item = -1;
+    uint32_t prev_vmask = 0u;
+    for (int j = 0; j < nmine; ++j) {
+        const int item = (int)blockIdx.x + j * (int)gridDim.x;
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};     // four independent accumulation chains (k-step mod 4)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int g = j * NCH + c;
+            vm_wait<(RING - 2) * PPC>();                   // my pieces of chunk g have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const u32x4 *rsrc = src_of(g + RING - 1);      // refill: into the slot chunk g-1 was read from
+            u32x4 *rdst = dst_of(g + RING - 1);
+            if (c == 0 && prev_item >= 0 && active) finish_tile(prev_item, prev_vmask);   // (partner's sums became visible at this barrier)
+            if (active && c / CPH == half) {
+                const u32x4 *lp = ring + (size_t)(g % RING) * CH * 64 + lane;
+                u32x4 af[PF + 1];
+#pragma unroll
+                for (int t = 0; t < PF; ++t) af[t] = lp[t * 64];
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int s = (c % CPH) * CH + t;      // k-step within my K-half
+                    if (t + PF < CH) af[(t + PF) % (PF + 1)] = lp[(t + PF) * 64];
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[t % (PF + 1)]);
+                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qreg[s]);
+                    if ((t & 3) == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c0, 0, 0, 0);
+                    else if ((t & 3) == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c1, 0, 0, 0);
+                    else if ((t & 3) == 2) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c2, 0, 0, 0);
+                    else c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c3, 0, 0, 0);
+                    if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);     // one wave per SIMD: DMA issues go between the MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c % CPH == CPH - 1) {                  // my K-half of this tile is complete: fold, hand the partner its 8 registers
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[r] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                    u32x4 *mx = xch + (size_t)wave * 2 * 64 + lane;
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = half ? part[i] : part[8 + i];   // the registers the PARTNER owns
+                    mx[0] = __builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]});
+                    mx[64] = __builtin_bit_cast(u32x4, f32x4{o[4], o[5], o[6], o[7]});
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
+            }
+        }
+        prev_item = item;
+        prev_vmask = rowmask[(int64_t)item * tile_stride];   // wave-uniform -> scalar load
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the last tile's partial sums are visible
+    if (prev_item >= 0 && active) finish_tile(prev_item, prev_vmask);
+
+    if (MODE == 1) {
+        // hand the workgroup's candidates over to the per-query lists (as k_scan does)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is done with the LDS, and its list stores have completed
+        unsigned int *wc = reinterpret_cast<unsigned int *>(lds);   // [WAVES] counts, [64] hist, [64] base, [64] off
+        unsigned int *hist = wc + WAVES;
+        unsigned int *base = hist + 64;
+        unsigned int *off = base + 64;
+        if (lane == 0) {
+            wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+            atomicMax(&status->max_wave_cnt, wcnt);
+            if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
+        }
+        if (tid < 64) {
+            hist[tid] = 0u;
+            off[tid] = 0u;
+        }
+        __syncthreads();
+        const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
+        __syncthreads();
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wc[w];
+            for (unsigned int e = tid; e < n; e += WAVES * 64) {
+                const u32x4 c = wl[(size_t)w * wave_cap + e];
+                const unsigned int q = c.z & 63u;
+                const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+                if (idx < (unsigned int)qcap) {
+                    u32x2 o;
+                    o.x = c.x;
+                    o.y = c.y;
+                    qlist[(size_t)q * qcap + idx] = o;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
 
 // k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
@@ -511,12 +742,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
 // issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's (one 32-query
 // block per wave instead of two).  nblk = number of 32-query blocks in use: waves beyond it only move data.
-template <int N>
-__device__ __forceinline__ void vm_wait()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(512) void k_scan_wide(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,

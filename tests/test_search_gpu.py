@@ -485,3 +485,34 @@ def test_wide_scan_equals_the_64_query_passes_and_survives_overflow(gpu, monkeyp
     assert np.array_equal(fr, wr) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
     wide.close()
     narrow.close()
+
+
+def test_ring_scan_equals_the_streaming_scan(gpu, monkeypatch):
+    """k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs, half-tile seeding) and k_scan (corpus straight
+    into registers) nominate differently; the canonical re-score decides both: identical bytes -- also with a filter,
+    tombstones, a short batch (one query block), k beyond the row count, and through the regrow path."""
+    ffi = _ffi()
+    rng = np.random.default_rng(99)
+    n = 70001
+    x = rng.standard_normal((n, D), dtype=np.float32)
+    x[500:900] = x[3] + 1e-3 * rng.standard_normal((400, D), dtype=np.float32)
+    codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
+    q = rng.standard_normal((64, D), dtype=np.float32)
+    q[5] = x[3]
+    dead = rng.choice(n, 5000, replace=False)
+    res = {}
+    for mode in ("ring", "stream"):
+        monkeypatch.setenv("CODERAG_HIP_SCAN", mode)
+        idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n, n_code_cols=1)
+        idx.append(x, codes)
+        idx.tombstone(dead)
+        out = [idx.search(q, 100), idx.search(q[:7], 10, filters=[(0, 1)]), idx.search(q[:33], 1000), idx.search(q[:1], 5)]
+        idx.set_tuning(force_fallback=1)
+        out.append(idx.search(q, 100))
+        assert idx.stats()["fallback_used"] == 1
+        res[mode] = out
+        idx.close()
+    monkeypatch.delenv("CODERAG_HIP_SCAN")
+    for a, b in zip(res["ring"], res["stream"]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(res["ring"][0][1], res["ring"][4][1])
