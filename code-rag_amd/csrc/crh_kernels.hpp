@@ -500,8 +500,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // k_scan streams every corpus tile straight into MFMA operand registers; its loads alone reach 6.97 TB/s and the scan 96-97 %
 // of that.  The LDS-DMA ring built for k_scan_wide moves data faster still (7.0 TB/s with all its waits and barriers), but a
 // wave that holds a whole 32-query block runs one dependent MFMA chain of KSTEPS links per tile (~120 cycles per link), which
-// is slower than the data.  k_scan_ring splits K instead: 4 waves = 2 query blocks x 2 K-halves, ONE wave per SIMD; a wave
-// keeps its block's fragments of its K-half in registers (KSTEPS/2 x 4), accumulates its chunks of a tile on FOUR alternating
+// is slower than the data.  k_scan_ring splits K instead: 4 waves = 2 query blocks x 2 K-halves (even / odd k-steps), ONE wave
+// per SIMD; a wave keeps its block's fragments of its k-steps in registers (KSTEPS/2 x 4), accumulates them on FOUR alternating
 // accumulators (independent chains), folds them, and swaps half of the 16 partial-sum registers with its partner through
 // 8 KB of LDS: wave (block b, half 0) ends up with the complete scores of accumulator registers 0-7 (rows 0-3, 8-11 [+4 for
 // the upper lanes]), wave (b, 1) with registers 8-15, and each thresholds / nominates its own 16 rows.  The exchange rides on
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void k_scan_ring(
     constexpr int NCH = KSTEPS / CH, CPH = KH / CH;        // chunks per tile / per K-half
     constexpr int RING = 144 / CH;                         // 144 KB of ring
     constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
-    constexpr int PF = 4;                                  // corpus fragments read ahead of their MFMAs
-    static_assert(KH % CH == 0 && CH % WAVES == 0 && CH > PF && (RING - 2) * PPC < 64 && RING >= 4, "ring geometry");
+    constexpr int PF = 3;                                  // corpus fragments read ahead of their MFMAs
+    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && CH / 2 > PF && CH / 2 >= PPC && (RING - 2) * PPC < 64 && RING >= 4, "ring geometry");
     __shared__ u32x4 lds[(RING * CH + 2 * WAVES) * 64];    // the ring, then 2 KB per wave for the partial-sum exchange
     u32x4 *ring = lds;
     u32x4 *xch = lds + RING * CH * 64;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_scan_ring(
 
     u32x4 qreg[KH];
 #pragma unroll
-    for (int s = 0; s < KH; ++s) qreg[s] = active ? qfrag[((size_t)blk * KSTEPS + half * KH + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    for (int s = 0; s < KH; ++s) qreg[s] = active ? qfrag[((size_t)blk * KSTEPS + 2 * s + half) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
     float t0 = 0.f;
     if (MODE == 1) t0 = active ? tau[blk * 32 + (lane & 31)] : INFINITY;
 
@@ -642,25 +642,28 @@ __global__ __launch_bounds__(256) void k_scan_ring(
             const u32x4 *rsrc = src_of(g + RING - 1);      // refill: into the slot chunk g-1 was read from
             u32x4 *rdst = dst_of(g + RING - 1);
             if (c == 0 && prev_item >= 0 && active) finish_tile(prev_item, prev_vmask);   // (partner's sums became visible at this barrier)
-            if (active && c / CPH == half) {
-                const u32x4 *lp = ring + (size_t)(g % RING) * CH * 64 + lane;
+            if (active) {
+                // K is split by k-step PARITY (half 0: even k-steps, half 1: odd), so every chunk carries CH/2 MFMAs for every
+                // wave: with K cut into two contiguous halves only two of the four waves worked on a chunk and the scan ran at
+                // the pace of their MFMAs (3.0 ms), not of the data
+                const u32x4 *lp = ring + (size_t)(g % RING) * CH * 64 + (size_t)half * 64 + lane;
                 u32x4 af[PF + 1];
 #pragma unroll
-                for (int t = 0; t < PF; ++t) af[t] = lp[t * 64];
+                for (int u = 0; u < PF; ++u) af[u] = lp[u * 128];
 #pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const int s = (c % CPH) * CH + t;      // k-step within my K-half
-                    if (t + PF < CH) af[(t + PF) % (PF + 1)] = lp[(t + PF) * 64];
-                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[t % (PF + 1)]);
+                for (int u = 0; u < CH / 2; ++u) {
+                    const int s = c * (CH / 2) + u;        // index among my k-steps of this tile (k-step 2*s + half)
+                    if (u + PF < CH / 2) af[(u + PF) % (PF + 1)] = lp[(u + PF) * 128];
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[u % (PF + 1)]);
                     const bf16x8 qb = __builtin_bit_cast(bf16x8, qreg[s]);
-                    if ((t & 3) == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c0, 0, 0, 0);
-                    else if ((t & 3) == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c1, 0, 0, 0);
-                    else if ((t & 3) == 2) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c2, 0, 0, 0);
+                    if ((s & 3) == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c0, 0, 0, 0);
+                    else if ((s & 3) == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c1, 0, 0, 0);
+                    else if ((s & 3) == 2) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c2, 0, 0, 0);
                     else c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c3, 0, 0, 0);
-                    if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);     // one wave per SIMD: DMA issues go between the MFMAs
+                    if (u < PPC) issue_piece(rsrc, rdst, u);     // one wave per SIMD: DMA issues go between the MFMAs
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (c % CPH == CPH - 1) {                  // my K-half of this tile is complete: fold, hand the partner its 8 registers
+                if (c == NCH - 1) {                        // the tile is complete: fold the chains, hand the partner its 8 registers
 #pragma unroll
                     for (int r = 0; r < 16; ++r) part[r] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
                     u32x4 *mx = xch + (size_t)wave * 2 * 64 + lane;
