@@ -230,8 +230,9 @@ int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, 
     return CRH_OK;
 }
 
-// the ring scan (<= 64 queries): 4 waves per workgroup, each sees every tile of its workgroup for its block's 16 rows
-constexpr int kRingWaves = 4;
+// the ring scan (<= 64 queries): two computing waves per workgroup, each sees EVERY tile of its workgroup for its 32 queries
+// (k_scan: 16 waves share them), so the workgroup's share of the candidate workspace is cut into 2 lists of 8 x wave_cap
+constexpr int kRingWaves = 2;
 template <int MODE>
 int launch_scan_ring(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
                      SearchStatus *stt)
@@ -307,8 +308,7 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
         CRH_TRY(launch_scan_ring<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else
         CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
-    const int GS = ring ? 2 * G : G;     // the ring scan seeds with one maximum per HALF tile
-    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)GS * 4, st, h->gmax, GS, k, margin, nq, h->tau, qstride);
+    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau, qstride);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
     if (wide)

@@ -498,22 +498,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
 // ------------------------------------------------------------------ the ring scan (<= 64 queries, corpus through LDS)
 
 // k_scan streams every corpus tile straight into MFMA operand registers; its loads alone reach 6.97 TB/s and the scan 96-97 %
-// of that.  The LDS-DMA ring built for k_scan_wide moves data faster still (7.0 TB/s with all its waits and barriers), but a
-// wave that holds a whole 32-query block runs one dependent MFMA chain of KSTEPS links per tile (~120 cycles per link), which
-// is slower than the data.  k_scan_ring splits K instead: 4 waves = 2 query blocks x 2 K-halves (even / odd k-steps), ONE wave
-// per SIMD; a wave keeps its block's fragments of its k-steps in registers (KSTEPS/2 x 4), accumulates them on FOUR alternating
-// accumulators (independent chains), folds them, and swaps half of the 16 partial-sum registers with its partner through
-// 8 KB of LDS: wave (block b, half 0) ends up with the complete scores of accumulator registers 0-7 (rows 0-3, 8-11 [+4 for
-// the upper lanes]), wave (b, 1) with registers 8-15, and each thresholds / nominates its own 16 rows.  The exchange rides on
-// the ring's barriers: a tile's reduction and epilogue run right after the first barrier of the NEXT tile.
+// of that.  An LDS-DMA ring moves data faster still: 7.0 TB/s with all its waits and barriers (profiles/r02_wide_scan.md).
+// k_scan_ring: a workgroup is 4 waves, ONE per SIMD.  Waves 0 and 1 each keep ONE 32-query block as MFMA B fragments in
+// registers for the whole kernel (KSTEPS x 4: 192 at dim 768) and run the block's dot products on NC alternating accumulators
+// -- a single dependent chain of v_mfma_f32_32x32x16_bf16 advances only every ~120 cycles, so a wave alone on its SIMD needs
+// several independent chains; they are added once per tile.  Waves 2 and 3 compute nothing: they keep the ring fed (their
+// DMA issues come right after each barrier; the computing waves issue theirs between MFMAs).
 // Ring: chunks of CH k-steps (12 KB at dim 768), RING chunks = 144 KB, RING-2 in flight; one raw s_barrier per chunk: each
-// wave first waits (counted vmcnt) for its own pieces of chunk g, so after the barrier chunk g has landed for everybody and
-// everybody is done with chunk g-1, whose slot chunk g+RING-1 is then issued into (computing waves issue their pieces
-// between their MFMAs, the others in a burst).  Past the workgroup's last tile the ring is refilled with chunks nobody reads,
-// so that the counted wait is ONE constant.  ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc drain
-// vmcnt before every LDS read).
-// Seed (MODE 0) writes one maximum per HALF tile (the 16 rows a wave owns): gmax[(2*item + half)*64 + query]; the k-th largest
-// of those is a lower bound of the k-th score just as with whole tiles (k half-tiles hold k distinct rows).
+// wave first waits (counted vmcnt) for its own pieces of chunk g+1, so after the barrier chunk g+1 has landed for everybody
+// (the fragment reads run ahead into it) and everybody is done with chunk g-1, whose slot chunk g+RING-1 is then issued into.
+// NCH divides RING, so a tile's chunks are contiguous in the ring.  Past the workgroup's last tile the ring is refilled with
+// chunks nobody reads, so that the counted wait is ONE constant.  ONE __shared__ object (a second one beside an LDS-DMA
+// target makes hipcc drain vmcnt before every LDS read).  Thresholds, candidate compaction and the hand-over are k_scan's.
+// A K-split variant (4 computing waves = 2 blocks x 2 K-halves, partial sums swapped through LDS) was built first: 3.0 ms
+// with contiguous halves, 2.53 with even / odd k-steps -- the fold, the exchange and four short MFMA bursts per tile cost more
+// than they saved; two computing waves beside two pure movers is both simpler and faster.
 template <int N>
 __device__ __forceinline__ void vm_wait()
 {
@@ -528,28 +527,25 @@ __global__ __launch_bounds__(256) void k_scan_ring(
     u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
     constexpr int WAVES = 4;
-    constexpr int KH = KSTEPS / 2;                         // k-steps of a K-half
-    constexpr int CH = (KH % 16 == 0) ? 16 : 12;           // k-steps (1-KiB pieces) per ring chunk
-    constexpr int NCH = KSTEPS / CH, CPH = KH / CH;        // chunks per tile / per K-half
-    constexpr int RING = 144 / CH;                         // 144 KB of ring
+    constexpr int CH = (KSTEPS % 16 == 0) ? 16 : 12;       // k-steps (1-KiB pieces) per ring chunk
+    constexpr int NCH = KSTEPS / CH;                       // chunks per tile
+    constexpr int RING = (144 / CH / NCH) * NCH;           // <= 144 KB of ring, whole tiles
     constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
-    constexpr int PF = 3;                                  // corpus fragments read ahead of their MFMAs
-    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && CH / 2 > PF && CH / 2 >= PPC && (RING - 2) * PPC < 64 && RING >= 4, "ring geometry");
-    __shared__ u32x4 lds[(RING * CH + 2 * WAVES) * 64];    // the ring, then 2 KB per wave for the partial-sum exchange
-    u32x4 *ring = lds;
-    u32x4 *xch = lds + RING * CH * 64;
+    constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
+    constexpr int NC = KSTEPS >= 96 ? 2 : 4;               // independent accumulation chains per computing wave
+    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && RING >= 4 && KSTEPS > PF && (RING - 3) * PPC < 64, "ring geometry");
+    __shared__ u32x4 ring[RING * CH * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lh = lane >> 5;
-    const int blk = wave & 1, half = wave >> 1;
-    const bool active = blk < nblk;
+    const int h = lane >> 5;
+    const bool active = wave < nblk;                       // nblk <= 2: waves 2 and 3 never compute
 
-    u32x4 qreg[KH];
+    u32x4 qreg[KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KH; ++s) qreg[s] = active ? qfrag[((size_t)blk * KSTEPS + 2 * s + half) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    for (int s = 0; s < KSTEPS; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
     float t0 = 0.f;
-    if (MODE == 1) t0 = active ? tau[blk * 32 + (lane & 31)] : INFINITY;
+    if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
 
     const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
@@ -574,50 +570,82 @@ __global__ __launch_bounds__(256) void k_scan_ring(
         }
     }
 
-    f32x16 part = {0};                  // this wave's partial scores of the tile just finished (its K-half)
-    // complete the 8 accumulator registers this wave owns with the partner's partial sums and nominate / take the maximum
-    auto finish_tile = [&](int item, uint32_t vmask) {
-        const int64_t tile = (int64_t)item * tile_stride;
-        const u32x4 *px = xch + (size_t)(blk + 2 * (1 - half)) * 2 * 64 + lane;     // what the partner wave left for me
-        const f32x4 p0 = __builtin_bit_cast(f32x4, px[0]), p1 = __builtin_bit_cast(f32x4, px[64]);
-        float sc[8];
+    if (!active) {   // a wave without queries only moves data: the same waits, barriers and refills, nothing else
+        for (int g = 0; g < nmine * NCH; ++g) {
+            vm_wait<(RING - 3) * PPC>();
+            __builtin_amdgcn_s_barrier();
+            const u32x4 *rsrc = src_of(g + RING - 1);
+            u32x4 *rdst = dst_of(g + RING - 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float mine = half ? part[8 + i] : part[i], theirs = i < 4 ? p0[i] : p1[i - 4];   // (selects, not indexed registers)
-            sc[i] = half ? theirs + mine : mine + theirs;          // always (K-half 0) + (K-half 1): the two waves agree
+            for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
         }
+    }
+    for (int j = 0; active && j < nmine; ++j) {
+        const int item = (int)blockIdx.x + j * (int)gridDim.x;
+        const int64_t tile = (int64_t)item * tile_stride;
+        const u32x4 *lp = ring + (size_t)((j * NCH) % RING) * CH * 64 + lane;
+        f32x16 acc[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] = f32x16{0};
+        u32x4 af[PF + 1];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int g = j * NCH + c;
+            vm_wait<(RING - 3) * PPC>();                   // my pieces of chunk g+1 have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const u32x4 *rsrc = src_of(g + RING - 1);      // refill: into the slot chunk g-1 was read from
+            u32x4 *rdst = dst_of(g + RING - 1);
+            if (c == 0) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int s = c * CH + t;
+                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
+                acc[s % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s % (PF + 1)]),
+                                                                      __builtin_bit_cast(bf16x8, qreg[s]), acc[s % NC], 0, 0, 0);
+                if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);     // DMA issues go between the MFMAs
+                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
+            }
+        }
+        f32x16 a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = NC == 4 ? (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[NC - 1][r]) : acc[0][r] + acc[NC - 1][r];
+        const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
+
         if (MODE == 0) {
             float m0 = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = half * 8 + i;
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? sc[i] : -INFINITY);
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? a0[r] : -INFINITY);
             }
             m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            if (lh == 0) gmax[((size_t)item * 2 + half) * 64 + blk * 32 + lane] = m0;
+            if (h == 0) gmax[(size_t)item * 64 + wave * 32 + lane] = m0;
         } else {
-            float m0 = sc[0];
+            float m0 = a0[0];
 #pragma unroll
-            for (int i = 1; i < 8; ++i) m0 = fmaxf(m0, sc[i]);
+            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, a0[r]);
             if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
-                uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)lh;
-                asm volatile("" : "+v"(rowbase));   // keep the row numbers out of the loop-invariant registers (rare path)
+                uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
+                asm volatile("" : "+v"(rowbase));   // keep the 16 row numbers out of the loop-invariant registers (rare path)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = half * 8 + i;
+                for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2);
-                    const int rbit = row + 4 * lh;
-                    const bool pass = ((vmask >> rbit) & 1u) && (sc[i] >= t0);
+                    const int rbit = row + 4 * h;
+                    const float sc = a0[r];
+                    const bool pass = ((vmask >> rbit) & 1u) && (sc >= t0);
                     const unsigned long long pm = __ballot(pass);
                     if (pm != 0ull) {
                         const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
                         const unsigned int pos = wcnt + pre;
                         if (pass && pos < (unsigned int)wave_cap) {
                             u32x4 e;
-                            e.x = f32_bits(sc[i]);
+                            e.x = f32_bits(sc);
                             e.y = rowbase + row;
-                            e.z = (uint32_t)(blk * 32 + (lane & 31));
+                            e.z = (uint32_t)(wave * 32 + (lane & 31));
                             e.w = 0u;
                             mylist[pos] = e;
                         }
@@ -626,70 +654,13 @@ __global__ __launch_bounds__(256) void k_scan_ring(
                 }
             }
         }
-    };
-
-    int prev_item = -1;
-    uint32_t prev_vmask = 0u;
-    for (int j = 0; j < nmine; ++j) {
-        const int item = (int)blockIdx.x + j * (int)gridDim.x;
-        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};     // four independent accumulation chains (k-step mod 4)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int g = j * NCH + c;
-            vm_wait<(RING - 2) * PPC>();                   // my pieces of chunk g have landed
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const u32x4 *rsrc = src_of(g + RING - 1);      // refill: into the slot chunk g-1 was read from
-            u32x4 *rdst = dst_of(g + RING - 1);
-            if (c == 0 && prev_item >= 0 && active) finish_tile(prev_item, prev_vmask);   // (partner's sums became visible at this barrier)
-            if (active) {
-                // K is split by k-step PARITY (half 0: even k-steps, half 1: odd), so every chunk carries CH/2 MFMAs for every
-                // wave: with K cut into two contiguous halves only two of the four waves worked on a chunk and the scan ran at
-                // the pace of their MFMAs (3.0 ms), not of the data
-                const u32x4 *lp = ring + (size_t)(g % RING) * CH * 64 + (size_t)half * 64 + lane;
-                u32x4 af[PF + 1];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) af[u] = lp[u * 128];
-#pragma unroll
-                for (int u = 0; u < CH / 2; ++u) {
-                    const int s = c * (CH / 2) + u;        // index among my k-steps of this tile (k-step 2*s + half)
-                    if (u + PF < CH / 2) af[(u + PF) % (PF + 1)] = lp[(u + PF) * 128];
-                    const bf16x8 xa = __builtin_bit_cast(bf16x8, af[u % (PF + 1)]);
-                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qreg[s]);
-                    if ((s & 3) == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c0, 0, 0, 0);
-                    else if ((s & 3) == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c1, 0, 0, 0);
-                    else if ((s & 3) == 2) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c2, 0, 0, 0);
-                    else c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, qb, c3, 0, 0, 0);
-                    if (u < PPC) issue_piece(rsrc, rdst, u);     // one wave per SIMD: DMA issues go between the MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (c == NCH - 1) {                        // the tile is complete: fold the chains, hand the partner its 8 registers
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part[r] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
-                    u32x4 *mx = xch + (size_t)wave * 2 * 64 + lane;
-                    float o[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = half ? part[i] : part[8 + i];   // the registers the PARTNER owns
-                    mx[0] = __builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]});
-                    mx[64] = __builtin_bit_cast(u32x4, f32x4{o[4], o[5], o[6], o[7]});
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
-            }
-        }
-        prev_item = item;
-        prev_vmask = rowmask[(int64_t)item * tile_stride];   // wave-uniform -> scalar load
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                        // the last tile's partial sums are visible
-    if (prev_item >= 0 && active) finish_tile(prev_item, prev_vmask);
 
     if (MODE == 1) {
         // hand the workgroup's candidates over to the per-query lists (as k_scan does)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // every wave is done with the LDS, and its list stores have completed
-        unsigned int *wc = reinterpret_cast<unsigned int *>(lds);   // [WAVES] counts, [64] hist, [64] base, [64] off
+        __syncthreads();   // every wave is done with the ring, and its list stores have completed
+        unsigned int *wc = reinterpret_cast<unsigned int *>(ring);   // [WAVES] counts, [64] hist, [64] base, [64] off
         unsigned int *hist = wc + WAVES;
         unsigned int *base = hist + 64;
         unsigned int *off = base + 64;
@@ -704,14 +675,14 @@ __global__ __launch_bounds__(256) void k_scan_ring(
         }
         __syncthreads();
         const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
-        for (int w = 0; w < WAVES; ++w) {
+        for (int w = 0; w < 2; ++w) {
             const unsigned int n = wc[w];
             for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
         }
         __syncthreads();
         if (tid < 64) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
         __syncthreads();
-        for (int w = 0; w < WAVES; ++w) {
+        for (int w = 0; w < 2; ++w) {
             const unsigned int n = wc[w];
             for (unsigned int e = tid; e < n; e += WAVES * 64) {
                 const u32x4 c = wl[(size_t)w * wave_cap + e];
