@@ -47,7 +47,7 @@ struct Pending {
 struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
-    bool use_ring = true;  // <= 64 queries: k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs) instead of k_scan
+    bool use_ring = false;  // <= 64 queries: k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs) instead of k_scan
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
@@ -431,9 +431,12 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     crh_index *h = new crh_index();
     h->dim = dim;
     h->ksteps = dim / 16;
-    {   // CODERAG_HIP_SCAN=stream selects k_scan (corpus straight into registers) for the <= 64-query passes: A/B timing only
+    {   // CODERAG_HIP_SCAN=ring selects k_scan_ring (corpus through the LDS-DMA ring) for the <= 64-query passes instead of
+        // k_scan (corpus straight into registers).  Measured at 10M x 768, 64 queries: k_scan 2.30 ms, k_scan_ring 2.34 ms
+        // (profiles/r02_wide_scan.md) -- the ring's data path is faster (7.0 vs 6.97 TB/s loads-only), but its two computing
+        // waves cannot hide the per-tile epilogue the way k_scan's sixteen do; it stays an option, not the default
         const char *e = getenv("CODERAG_HIP_SCAN");
-        h->use_ring = !(e && strcmp(e, "stream") == 0);
+        h->use_ring = e && strcmp(e, "ring") == 0;
     }
     h->batch_q = (dim > 1024 && !h->use_ring) ? 32 : 64;   // (k_scan's 64-query image does not fit LDS at dim 1536)
     h->wide_ok = dim <= 768 && getenv("CODERAG_HIP_NO_WIDE_SCAN") == nullptr;   // (the env switch exists for A/B timing only)

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_scan_ring(
     constexpr int RING = (144 / CH / NCH) * NCH;           // <= 144 KB of ring, whole tiles
     constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
     constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
-    constexpr int NC = KSTEPS >= 96 ? 2 : 4;               // independent accumulation chains per computing wave
+    constexpr int NC = 2;                                  // independent accumulation chains per computing wave (4: 2.47 ms, the fold costs more than the chains gain)
     static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && RING >= 4 && KSTEPS > PF && (RING - 3) * PPC < 64, "ring geometry");
     __shared__ u32x4 ring[RING * CH * 64];
     const int tid = threadIdx.x;

@@ -248,7 +248,7 @@ def test_other_embedding_dimensions(gpu, dim, bf16):
     s, r = idx.search(q, 20)
     es, er = orc.cosine_search(x, q, 20, bf16=bf16)
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
-    assert idx.stats()["batches"] == {384: 1, 1024: 2, 1536: 2}[dim]      # 70 queries: one wide pass | 64 + 6 | 64 + 6 (ring scan: 64 per pass at every width)
+    assert idx.stats()["batches"] == {384: 1, 1024: 2, 1536: 3}[dim]      # 70 queries: one wide pass | 64 + 6 | 32 + 32 + 6
     idx.close()
     with pytest.raises(ffi.NativeError):
         ffi.Index(100, ffi.DTYPE_F32, 64)
