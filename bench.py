@@ -686,23 +686,24 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
     rng = np.random.default_rng(1234 + rank)
     lengths = np.clip(np.round(np.exp(rng.normal(np.log(160.0), 0.8, n_chunks))), 8, 512).astype(np.int64)
     dev = torch.device("cuda", local_rank)
+    # packed batches (no padding: rows back to back on one token axis, attention / gather / pool take the row offsets):
+    # what HipUniXcoder.embed_ids / embed_bodies submit; the ids are staged on the device before the timed region
     batches = []
-    for rows, L in model.plan_batches(lengths, max_tokens=65536):
-        host = np.full((len(rows), L), cfg.pad_token_id, dtype=np.int32)
-        for r, i in enumerate(rows):
-            n = int(lengths[i])
-            host[r, :n] = np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, n - 4), [2]]) if n >= 4 else [0, 5, 2, 2][:n]
-        batches.append(torch.from_numpy(host).to(dev))
-    log(f"encoder leg: {n_chunks} chunks in {len(batches)} length-bucketed batches, weights resident")
-    for ids in batches[:3]:
-        model.forward_ids(ids)
+    id_rows = [np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, int(n) - 4), [2]]).astype(np.int32) if n >= 4
+               else np.asarray([0, 5, 2, 2][:int(n)], np.int32) for n in lengths]
+    for rows, _ in model.plan_batches(lengths, max_tokens=65536, max_rows=4096, packed=True):
+        flat, off, Lmax = model.pack_rows(id_rows, rows)
+        batches.append((torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), Lmax))
+    log(f"encoder leg: {n_chunks} chunks in {len(batches)} length-bucketed packed batches, weights resident")
+    for ids, off, Lmax in batches[:3]:
+        model.forward_packed(ids, off, Lmax)
     torch.cuda.synchronize()
     log("encoder warm-up done")
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for ids in batches:
-        model.forward_ids(ids)
+    for ids, off, Lmax in batches:
+        model.forward_packed(ids, off, Lmax)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -713,10 +714,11 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
         dt = float(t.item())
     log(f"encoder timed: {dt:.3f} s")
     flops = float(sum(drv.flops_per_chunk(int(n), cfg) for n in lengths))
-    padded_tokens = int(sum(int(b.numel()) for b in batches))
+    padded_tokens = int(sum(int(b[0].numel()) for b in batches))      # tokens the kernels processed (packed: the real ones)
     res = {"metric": "chunks embedded/s (UniXcoder-geometry bf16 HIP encoder)", "value": world * n_chunks / dt, "unit": "chunks/s",
            "chunks_per_gpu": int(n_chunks), "seconds": dt, "mean_tokens": float(lengths.mean()), "true_tokens": int(lengths.sum()),
-           "padded_tokens": padded_tokens, "batches": len(batches), "dtype": "bf16 weights/activations, f32 accumulate/LN/softmax",
+           "padded_tokens": padded_tokens, "layout": "packed rows (no padding tokens)", "batches": len(batches),
+           "dtype": "bf16 weights/activations, f32 accumulate/LN/softmax",
            "data": "synthetic ids + seeded random RoBERTa-base-geometry weights (no checkpoint offline)",
            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops": flops}}

@@ -90,14 +90,19 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
                                                   const bf16_t *__restrict__ pos, const bf16_t *__restrict__ type0,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                   int pad_id, bf16_t *__restrict__ out, unsigned long long *__restrict__ kmask,
-                                                  int L, int D)
+                                                  int Lpad, int D, const int32_t *__restrict__ row_off)
 {
     extern __shared__ int posid[];  // [L]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *row = ids + (size_t)b * L;
-    const int nw = (L + 63) >> 6;                    // mask words per row (L is a multiple of 16, not necessarily of 64)
+    // packed rows (row_off != NULL): row b holds the tokens [row_off[b], row_off[b+1]) of a flat id array, no padding between
+    // rows; Lpad (a multiple of 16, >= every row) only sizes the mask stride and the grid.  Padded rows: L = Lpad tokens at b*Lpad.
+    const int64_t r0 = row_off ? (int64_t)row_off[b] : (int64_t)b * Lpad;
+    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
+    if ((int)blockIdx.y * 16 >= L && blockIdx.y != 0) return;      // (block y = 0 of a row always writes the row's mask words)
+    const int32_t *row = ids + r0;
+    const int nw = (Lpad + 63) >> 6;                 // mask words per row (Lpad is a multiple of 16, not necessarily of 64)
     __shared__ int wcnt[16];                       // real tokens per 64-token word (L <= 1024)
-    for (int t0 = wave * 64; t0 < L; t0 += 256) {  // validity bitmask, 64 tokens per wave step
+    for (int t0 = wave * 64; t0 < nw * 64; t0 += 256) {  // validity bitmask, 64 tokens per wave step (words past the row: 0)
         const bool v = (t0 + lane < L) && row[t0 + lane] != pad_id;
         const unsigned long long m = __ballot(v);
         if (lane == 0) {
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
     }
     __syncthreads();
     constexpr int per = 3;  // D == 768: 3 groups of 4 elements per lane
-    for (int t = blockIdx.y * 16 + wave; t < blockIdx.y * 16 + 16; t += 4) {   // L % 16 == 0
+    for (int t = blockIdx.y * 16 + wave; t < blockIdx.y * 16 + 16 && t < L; t += 4) {
         const bf16_t *w = word + (size_t)row[t] * D;
         const bf16_t *p = pos + (size_t)posid[t] * D;
         float x[12];
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
 #pragma unroll
         for (int i = 0; i < 4 * per; ++i) v += (x[i] - mu) * (x[i] - mu);
         const float rstd = rsqrtf(wave_sum(v) / D + eps);
-        bf16_t *o = out + ((size_t)b * L + t) * D;
+        bf16_t *o = out + (size_t)(r0 + t) * D;
 #pragma unroll
         for (int i = 0; i < per; ++i) {
             const int e = i * 256 + lane * 4;
@@ -531,18 +536,23 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 // Dynamic LDS: K image [L][64] then V image [L][64], both 128-B rows with the chunk XOR of lds_off().
 template <int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv, const unsigned long long *__restrict__ kmask,
-                                                  bf16_t *__restrict__ out, int L, int H, float scale_log2)
+                                                  bf16_t *__restrict__ out, int Lpad, int H, float scale_log2,
+                                                  const int32_t *__restrict__ row_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kv[];
-    unsigned char *Ks = kv, *Vs = kv + (size_t)((L + 63) & ~63) * 128;
+    unsigned char *Ks = kv, *Vs = kv + (size_t)((Lpad + 63) & ~63) * 128;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int ld = 3 * H * 64;
-    const bf16_t *base = qkv + (size_t)b * L * ld + h * 64;
-    const int nkt = (L + 63) >> 6;                   // 64-key tiles; the last one may reach past L (those keys are masked)
+    // packed rows (row_off != NULL): row b = tokens [row_off[b], row_off[b+1]) of the flat token axis; its 16-row query tiles and
+    // 64-key tiles may reach into the next row's tokens -- those keys are masked, those query rows are computed and NOT stored
+    const size_t r0 = row_off ? (size_t)row_off[b] : (size_t)b * Lpad;
+    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
+    const bf16_t *base = qkv + r0 * ld + h * 64;
+    const int nkt = (Lpad + 63) >> 6;                // mask words per row; a 64-key tile may reach past L (those keys are masked)
     const unsigned long long *km = kmask + (size_t)b * nkt;
-    const size_t last_row = (size_t)gridDim.y * L - 1;   // staging never reads past the end of the qkv buffer
+    const size_t last_row = (row_off ? (size_t)row_off[gridDim.y] : (size_t)gridDim.y * Lpad) - 1;   // never read past the buffer
 
     // last 64-key tile that holds a valid key: nothing beyond it is staged or visited
     int last = -1;
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
     const bf16_t *hbase = qkv + h * 64;
     for (int i = tid; i < Lk * 8; i += NW * 64) {
         const int r = i >> 3, c = i & 7;
-        size_t gr = (size_t)b * L + r;                // keys >= L belong to the next row (or nothing): loaded, never used
+        size_t gr = r0 + r;                           // keys >= L belong to the next row (or nothing): loaded, never used
         gr = gr < last_row ? gr : last_row;
         *reinterpret_cast<u32x4 *>(Ks + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(hbase + gr * ld + H * 64 + c * 8);
         *reinterpret_cast<u32x4 *>(Vs + lds_off(r, c)) = *reinterpret_cast<const u32x4 *>(hbase + gr * ld + 2 * H * 64 + c * 8);
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
     // Each wave works on QT 16-row query tiles AT ONCE so that every K fragment and every transposed V fragment it reads
     // from LDS feeds QT MFMAs: with one tile per wave the kernel moved 64 B/clk/wave through an LDS that delivers
     // 256 B/clk per CU -- LDS-bound at 8 waves by a factor of two (250 TFLOP/s at L = 512).
-    const int nqt = L >> 4;
+    const int nqt = (L + 15) >> 4;
     for (int qg = wave; qg * QT < nqt; qg += NW) {
         bf16x8 qf[QT][2];
         float mrun[QT], lrun[QT];
@@ -573,10 +583,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
         for (int qi = 0; qi < QT; ++qi) {
             const int q0 = (qg * QT + qi) * 16;
             live[qi] = q0 < L && q0 < Lk;
-            const int qr = live[qi] ? q0 + c16 : 0;
+            size_t qr = r0 + (live[qi] ? q0 + c16 : 0);
+            qr = qr < last_row ? qr : last_row;         // (a packed row's last tile may reach past the buffer's last token)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                qf[qi][ks] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qr * ld + 32 * ks + 8 * g);
+                qf[qi][ks] = *reinterpret_cast<const bf16x8 *>(qkv + qr * ld + h * 64 + 32 * ks + 8 * g);
             mrun[qi] = -INFINITY;
             lrun[qi] = 0.f;
 #pragma unroll
@@ -685,8 +696,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
             const int q0 = (qg * QT + qi) * 16;
-            if (q0 >= L) continue;                       // no such tile
-            bf16_t *orow = out + ((size_t)b * L + q0 + c16) * (H * 64) + h * 64;
+            if (q0 >= L || q0 + c16 >= L) continue;      // no such tile / a row of the NEXT packed row (never for padded rows: L % 16 == 0)
+            bf16_t *orow = out + (r0 + q0 + c16) * (H * 64) + h * 64;
             // rows past the last valid token (not live): never read as keys nor pooled; written as zeros to stay finite
             const float inv = (live[qi] && lrun[qi] > 0.f) ? 1.f / lrun[qi] : 0.f;
 #pragma unroll
@@ -707,14 +718,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
 // bit after the load: padded rows are real memory); the four partial sums are added in wave order.  (One thread per dim
 // walking every token behind a branch on its mask bit was a chain of L dependent loads: 31 us at B = 16, L = 128.)
 __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, const unsigned long long *__restrict__ kmask,
-                                              float *__restrict__ sent, int L, int D)
+                                              float *__restrict__ sent, int Lpad, int D, const int32_t *__restrict__ row_off)
 {
     __shared__ float part[4][64][2];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = blockIdx.x * 128 + lane * 2;
-    const int nw = (L + 63) >> 6;
+    const int nw = (Lpad + 63) >> 6;
     const unsigned long long *km = kmask + (size_t)b * nw;
-    const bf16_t *base = tok + (size_t)b * L * D + d;
+    const size_t r0 = row_off ? (size_t)row_off[b] : (size_t)b * Lpad;
+    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
+    const bf16_t *base = tok + r0 * D + d;
     float a0 = 0.f, a1 = 0.f;
     for (int t = wave; t < L; t += 32) {
         uint32_t v[8];
@@ -1207,7 +1220,20 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     return CRH_OK;
 }
 
+static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int L, int H, void *stream);
+
 int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream)
+{
+    return attn_launch(qkv, kmask, out, nullptr, B, L, H, stream);
+}
+
+int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int Lmax, int H, void *stream)
+{
+    if (!row_off) return fail(CRH_E_INVALID, "attn_packed: row_off is NULL");
+    return attn_launch(qkv, kmask, out, row_off, B, Lmax, H, stream);
+}
+
+static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int L, int H, void *stream)
 {
     if (!qkv || !kmask || !out) return fail(CRH_E_INVALID, "attn: NULL pointer");
     if (B <= 0 || H <= 0 || L <= 0 || L % 16 || L > 512) return fail(CRH_E_INVALID, "attn: B=%d L=%d H=%d (need L%%16==0, L<=512)", B, L, H);
@@ -1227,7 +1253,7 @@ int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<NW_, QT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256)); \
         }                                                                                                                       \
         hipLaunchKernelGGL((k_attn<NW_, QT_>), dim3(H, B), dim3(NW_ * 64), lds, st, (const bf16_t *)qkv,                        \
-                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2);                                 \
+                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2, row_off);                        \
     } while (0)
     static int force = -1;   // CODERAG_HIP_ATTN_CFG=<waves> (4, 8, 16; tuning only)
     if (force < 0) {
@@ -1252,7 +1278,18 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln: NULL pointer");
     if (B <= 0 || L <= 0 || L % 16 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%16==0, D==768)", B, L, D);
     hipLaunchKernelGGL(k_embed_ln, dim3(B, L / 16), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
-                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D);
+                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D,
+                       (const int32_t *)nullptr);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+int crh_embed_ln_packed(const int32_t *ids, const int32_t *row_off, const void *word, const void *pos, const void *type0, const float *gamma,
+                        const float *beta, float eps, int pad_id, void *out, uint64_t *kmask, int B, int Lmax, int D, void *stream)
+{
+    if (!ids || !row_off || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln_packed: NULL pointer");
+    if (B <= 0 || Lmax <= 0 || Lmax % 16 || Lmax > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln_packed: B=%d Lmax=%d D=%d (need Lmax%%16==0, D==768)", B, Lmax, D);
+    hipLaunchKernelGGL(k_embed_ln, dim3(B, Lmax / 16), dim3(256), (size_t)Lmax * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
+                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, Lmax, D, row_off);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -1262,7 +1299,16 @@ int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, in
     if (!tok || !kmask || !sent) return fail(CRH_E_INVALID, "pool: NULL pointer");
     if (B <= 0 || L <= 0 || L % 16 || D % 128) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
     hipLaunchKernelGGL(k_pool, dim3(D / 128, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
-                       (const unsigned long long *)kmask, sent, L, D);
+                       (const unsigned long long *)kmask, sent, L, D, (const int32_t *)nullptr);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int Lmax, int D, void *stream)
+{
+    if (!tok || !row_off || !kmask || !sent) return fail(CRH_E_INVALID, "pool_packed: NULL pointer");
+    if (B <= 0 || Lmax <= 0 || Lmax % 16 || D % 128) return fail(CRH_E_INVALID, "pool_packed: B=%d Lmax=%d D=%d", B, Lmax, D);
+    hipLaunchKernelGGL(k_pool, dim3(D / 128, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
+                       (const unsigned long long *)kmask, sent, Lmax, D, row_off);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -208,20 +208,66 @@ class HipUniXcoder:
         check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
         return sent
 
+    def forward_packed(self, ids, row_off, Lmax: int):
+        """The forward on a batch WITHOUT padding: ``ids`` int32 CUDA tensor [T] (the rows' tokens back to back), ``row_off``
+        int32 CUDA tensor [B + 1] (row b = ids[row_off[b]:row_off[b+1]]), ``Lmax`` a multiple of 16 >= every row's length.
+        Returns f32 [B, 768].  GEMMs and LayerNorms run on the T real tokens; attention, the embedding gather and the pool
+        take the row offsets (``crh_*_packed``).  Same arithmetic per token as :meth:`forward_ids`."""
+        torch, L_ = self._torch, ffi.lib()
+        ffi.use_device(self.device.index)
+        B, T = int(row_off.shape[0]) - 1, int(ids.shape[0])
+        cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        bf = torch.bfloat16
+        x = torch.empty((T, H), dtype=bf, device=self.device)
+        x1 = torch.empty((T, H), dtype=bf, device=self.device)
+        qkv = torch.empty((T, 3 * H), dtype=bf, device=self.device)
+        ctx = torch.empty((T, H), dtype=bf, device=self.device)
+        hid = torch.empty((T, F), dtype=bf, device=self.device)
+        kmask = torch.empty((B, (Lmax + 63) // 64), dtype=torch.int64, device=self.device)
+        sent = torch.empty((B, H), dtype=torch.float32, device=self.device)
+        px, px1, pqkv, pctx, phid, pkm, psent, poff = (int(t.data_ptr()) for t in (x, x1, qkv, ctx, hid, kmask, sent, row_off))
+        eps, check = cfg.layer_norm_eps, ffi.check
+        gemm, gemm_ln = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln
+        check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, Lmax, H, st))
+        for ly in self._layer_ptrs:
+            check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
+            check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, Lmax, cfg.num_heads, st))
+            check(gemm_ln(pctx, ly["o_w"], ly["o_b"], px, ly["ln1_g"], ly["ln1_b"], eps, px1, T, H, H, st))
+            check(gemm(px1, ly["f1_w"], ly["f1_b"], phid, T, F, H, 1, st))
+            check(gemm_ln(phid, ly["f2_w"], ly["f2_b"], px1, ly["ln2_g"], ly["ln2_b"], eps, px, T, H, F, st))
+        check(L_.crh_masked_mean_pool_packed(px, poff, pkm, psent, B, Lmax, H, st))
+        return sent
+
+    def pack_rows(self, id_rows, rows):
+        """Host side of a packed batch: (ids int32 [T], row_off int32 [B + 1], Lmax) for the id lists ``id_rows[i], i in rows``."""
+        lens = np.fromiter((len(id_rows[i]) for i in rows), dtype=np.int64, count=len(rows))
+        off = np.zeros(len(rows) + 1, dtype=np.int32)
+        np.cumsum(lens, out=off[1:])
+        flat = np.empty(int(off[-1]), dtype=np.int32)
+        for r, i in enumerate(rows):
+            flat[off[r]:off[r + 1]] = id_rows[i]
+        return flat, off, (int(lens.max()) + 15) // 16 * 16
+
     # ------------------------------------------------------------------ batching
-    def plan_batches(self, lengths, max_tokens: int = 65536, max_rows: int = 1024):
+    def plan_batches(self, lengths, max_tokens: int = 65536, max_rows: int = 1024, packed: bool = False):
         """Length-bucketed batches: rows sorted by length, each batch padded to its longest row rounded up to 16 (the
-        query-tile height of the attention kernel): ~4 % padded tokens on a mean-200 mix, against 16 % at granularity 64."""
+        query-tile height of the attention kernel): ~4 % padded tokens on a mean-200 mix, against 16 % at granularity 64.
+        ``packed=True``: the batches of :meth:`forward_packed` -- no padding at all, so a batch is filled to ``max_tokens`` REAL
+        tokens (the second element is still the longest row rounded up to 16: it sizes the attention launch)."""
         order = np.argsort(np.asarray(lengths), kind="stable")
-        batches, cur, cur_L = [], [], 0
+        batches, cur, cur_L, cur_T = [], [], 0, 0
         for i in order:
-            L = (int(lengths[i]) + 15) // 16 * 16
+            n = int(lengths[i])
+            L = (n + 15) // 16 * 16
             newL = max(cur_L, L)
-            if cur and (newL * (len(cur) + 1) > max_tokens or len(cur) >= max_rows):
+            full = (cur_T + n > max_tokens) if packed else (newL * (len(cur) + 1) > max_tokens)
+            if cur and (full or len(cur) >= max_rows):
                 batches.append((cur, cur_L))
-                cur, newL = [], L
+                cur, newL, cur_T = [], L, 0
             cur.append(int(i))
             cur_L = newL
+            cur_T += n
         if cur:
             batches.append((cur, cur_L))
         return batches
@@ -247,14 +293,14 @@ class HipUniXcoder:
             if len(x) > self.cfg.max_position_embeddings - 2:
                 raise ValueError(f"{len(x)} tokens exceed the position table ({self.cfg.max_position_embeddings - 2})")
         out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        for rows, L in self.plan_batches([len(x) for x in id_lists], max_tokens):
-            host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)
-            for r, i in enumerate(rows):
-                host[r, : len(id_lists[i])] = id_lists[i]
-            ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+        if any(len(x) == 0 for x in id_lists):
+            raise ValueError("an empty token list cannot be embedded (the reference's tokenize() always emits 4 specials)")
+        for rows, _ in self.plan_batches([len(x) for x in id_lists], max_tokens, max_rows=4096, packed=True):
+            flat, off, Lmax = self.pack_rows(id_lists, rows)
+            res = self.forward_packed(torch.from_numpy(flat).to(self.device), torch.from_numpy(off).to(self.device), Lmax)
             if n == 1:                     # the query path: no scatter through a device index
-                return self.forward_ids(ids)
-            out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
+                return res
+            out[torch.as_tensor(rows, device=self.device)] = res
         return out
 
     def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 65536):
@@ -267,17 +313,21 @@ class HipUniXcoder:
         blen = np.minimum(body_lens.astype(np.int64), max_length - 4)
         self._check_ids(body_ids[:, : int(blen.max()) if n else 0], blen)
         out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        for rows, L in self.plan_batches(blen + 4, max_tokens):
-            host = np.full((len(rows), L), self.cfg.pad_token_id, dtype=np.int32)
-            host[:, 0], host[:, 1], host[:, 2] = tok.cls_id, tok.enc_only_id, tok.sep_id
+        for rows, _ in self.plan_batches(blen + 4, max_tokens, max_rows=4096, packed=True):
+            lens = blen[rows] + 4
+            off = np.zeros(len(rows) + 1, dtype=np.int32)
+            np.cumsum(lens, out=off[1:])
+            flat = np.empty(int(off[-1]), dtype=np.int32)
+            flat[off[:-1]], flat[off[:-1] + 1], flat[off[:-1] + 2] = tok.cls_id, tok.enc_only_id, tok.sep_id
+            flat[off[1:] - 1] = tok.sep_id
             for r, i in enumerate(rows):
                 b = int(blen[i])
-                host[r, 3:3 + b] = body_ids[i, :b]
-                host[r, 3 + b] = tok.sep_id
-            ids = torch.from_numpy(host).to(self.device, non_blocking=False)
+                flat[off[r] + 3:off[r] + 3 + b] = body_ids[i, :b]
+            Lmax = (int(lens.max()) + 15) // 16 * 16
+            res = self.forward_packed(torch.from_numpy(flat).to(self.device), torch.from_numpy(off).to(self.device), Lmax)
             if n == 1:
-                return self.forward_ids(ids)
-            out[torch.as_tensor(rows, device=self.device)] = self.forward_ids(ids)
+                return res
+            out[torch.as_tensor(rows, device=self.device)] = res
         return out
 
     def embed_texts(self, texts, max_length: int = 512, rows: str = "list"):

@@ -29,6 +29,7 @@ EXPORTS = (
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
+    "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed",
 )
 # exported by lib/libcoderag_hip_debug.so only (same sources built with -DCRH_ENABLE_DEBUG; tools/ and kernel tests)
 DEBUG_EXPORTS = ("crh_debug_gemm_variant", "crh_debug_read_ceiling")
@@ -143,6 +144,9 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.crh_embed_ln_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
+    L.crh_attn_fwd_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.crh_masked_mean_pool_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -270,6 +270,19 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
 int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, int B, int L, int D,
                          void *stream);
 
+/* Packed rows: the same three kernels on a batch WITHOUT padding.  Row b of the batch is the tokens
+ * [row_off[b], row_off[b+1]) of one flat token axis (ids int32 [T], activations [T, ...], T = row_off[B]); Lmax (a multiple of
+ * 16, >= every row's length, <= 512) sizes the key-mask stride (ceil(Lmax/64) words per row) and the launch.  The GEMM /
+ * LayerNorm entry points above take T tokens as they are.  What it buys: the padded form rounds every row up to its bucket's
+ * length (a multiple of 16) -- ~4 % of the tokens of a mean-200 mix -- and every kernel of the forward pays for them. */
+int crh_embed_ln_packed(const int32_t *ids, const int32_t *row_off, const void *word, const void *pos, const void *type0,
+                        const float *gamma, const float *beta, float eps, int pad_id, void *out, uint64_t *kmask, int B,
+                        int Lmax, int D, void *stream);
+int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int Lmax, int H,
+                        void *stream);
+int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int Lmax,
+                                int D, void *stream);
+
 /* ------------------------------------------------------------- debug build only --------- */
 /* Exported ONLY by libcoderag_hip_debug.so (code-rag_amd/build.sh compiles the same sources a second time with
  * -DCRH_ENABLE_DEBUG for tools/ and the kernel-selection tests); the product library has no crh_debug_* symbol. */

@@ -368,3 +368,75 @@ def test_encoder_properties_on_the_bench_mix(gpu):
     assert np.abs(got - full[perm]).max() <= 3e-2 * scale[perm].max()
     rev = model.embed_ids(sub[::-1]).cpu().numpy()
     assert np.array_equal(rev[::-1], got)                                        # same batches, other input order: bit-identical
+
+
+# ---- packed rows (crh_*_packed): the forward without padding tokens
+def test_packed_forward_equals_the_padded_forward(gpu):
+    """Rows back to back on one token axis (attention / embedding gather / pool take row offsets, GEMMs and LayerNorms see only
+    real tokens) against the padded batch: the arithmetic per token is the same, so the sentence vectors agree to accumulation
+    noise (other GEMM tiles see other neighbours; the kernels themselves are the same)."""
+    torch, ffi, dev = _env()
+    from coderag_amd import encoder as drv
+    cfg = drv.EncoderConfig(num_layers=3)
+    model = drv.HipUniXcoder(drv.synthetic_weights(cfg, 7), cfg, drv.HashTokenizer(cfg.vocab_size), 0)
+    rng = np.random.default_rng(5)
+    lens = [5, 16, 17, 31, 32, 33, 64, 100, 127, 128, 129, 200, 255, 256, 300, 511, 512, 4, 63, 65]
+    rows = [np.concatenate([[0, 6, 2], rng.integers(3, cfg.vocab_size, n - 4), [2]]).astype(np.int32) for n in lens]
+    rows = [np.where(r == cfg.pad_token_id, 7, r).astype(np.int32) for r in rows]
+    rows[8][40] = cfg.pad_token_id                          # an interior pad token: masked as key, skipped by positions and pool
+    L = 512
+    padded = np.full((len(rows), L), cfg.pad_token_id, np.int32)
+    for i, r in enumerate(rows):
+        padded[i, : len(r)] = r
+    want = model.forward_ids(torch.from_numpy(padded).to(dev)).cpu().numpy()
+    order = list(range(len(rows)))
+    flat, off, Lmax = model.pack_rows(rows, order)
+    assert Lmax == 512 and off[-1] == sum(lens)
+    got = model.forward_packed(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), Lmax).cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    assert np.abs(got - want).max() <= 2e-2 * scale.max(), np.abs(got - want).max() / scale.max()
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos.min() >= 0.9998, cos.min()
+    # twice the same call: identical bits; another row order: every row keeps its vector (to noise)
+    again = model.forward_packed(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), Lmax).cpu().numpy()
+    assert np.array_equal(got, again)
+    perm = rng.permutation(len(rows)).tolist()
+    f2, o2, L2 = model.pack_rows(rows, perm)
+    g2 = model.forward_packed(torch.from_numpy(f2).to(dev), torch.from_numpy(o2).to(dev), L2).cpu().numpy()
+    assert np.abs(g2 - got[perm]).max() <= 2e-2 * scale.max()
+
+
+def test_packed_attention_does_not_touch_its_neighbours(gpu):
+    """crh_attn_fwd_packed on ragged rows: every row equals torch softmax attention over ITS tokens only; the rows' last query
+    tiles reach into the next row's tokens (computed, never stored), and nothing is written past the last token."""
+    torch, ffi, dev = _env()
+    H = 12
+    lens = [7, 16, 33, 100, 64, 1, 250, 129]
+    off = np.zeros(len(lens) + 1, np.int32)
+    np.cumsum(lens, out=off[1:])
+    T, Lmax = int(off[-1]), 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    qkv = torch.randn((T, 3 * H * 64), generator=g).to(dev, torch.bfloat16)
+    nw = (Lmax + 63) // 64
+    km = torch.zeros((len(lens), nw), dtype=torch.int64)
+    for b, n in enumerate(lens):
+        bits = [(1 if t < n else 0) for t in range(nw * 64)]
+        if b == 3:
+            bits[50] = 0                                     # an interior masked key
+        for w in range(nw):
+            v = sum(bit << i for i, bit in enumerate(bits[w * 64:(w + 1) * 64]))
+            km[b, w] = v - (1 << 64) if v >= (1 << 63) else v
+    out = torch.full((T + 16, H * 64), 7.0, dtype=torch.bfloat16, device=dev)           # 16 guard rows
+    ffi.check(ffi.lib().crh_attn_fwd_packed(qkv.data_ptr(), torch.from_numpy(off).to(dev).data_ptr(), km.to(dev).data_ptr(), out.data_ptr(),
+                                            len(lens), Lmax, H, 0))
+    torch.cuda.synchronize()
+    assert bool((out[T:] == 7.0).all())
+    for b, n in enumerate(lens):
+        x = qkv[off[b]:off[b + 1]].float()
+        q, k, v = (t.reshape(n, H, 64).transpose(0, 1) for t in x.split(H * 64, dim=-1))
+        s = q @ k.transpose(-1, -2) * 0.125
+        if b == 3:
+            s[:, :, 50] = float("-inf")
+        ref = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(n, H * 64)
+        _close(torch, out[off[b]:off[b + 1]], ref, rel=2 ** -6, abs_=1.5e-2)
