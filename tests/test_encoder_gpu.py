@@ -432,8 +432,8 @@ def test_packed_attention_does_not_touch_its_neighbours(gpu):
             v = sum(bit << i for i, bit in enumerate(bits[w * 64:(w + 1) * 64]))
             km[b, w] = v - (1 << 64) if v >= (1 << 63) else v
     out = torch.full((T + 16, H * 64), 7.0, dtype=torch.bfloat16, device=dev)           # 16 guard rows
-    ffi.check(ffi.lib().crh_attn_fwd_packed(qkv.data_ptr(), torch.from_numpy(off).to(dev).data_ptr(), km.to(dev).data_ptr(), out.data_ptr(),
-                                            len(lens), Lmax, H, 0))
+    off_d, km_d = torch.from_numpy(off).to(dev), km.to(dev)       # (named: a temporary would be freed -- and its block reused -- before the kernel reads it)
+    ffi.check(ffi.lib().crh_attn_fwd_packed(qkv.data_ptr(), off_d.data_ptr(), km_d.data_ptr(), out.data_ptr(), len(lens), Lmax, H, 0))
     torch.cuda.synchronize()
     assert bool((out[T:] == 7.0).all())
     for b, n in enumerate(lens):
