@@ -330,18 +330,62 @@ class HipUniXcoder:
             out[torch.as_tensor(rows, device=self.device)] = res
         return out
 
+    PIPELINE_CHUNK = 4096      # texts per stage of the text pipeline below
+
     def embed_texts(self, texts, max_length: int = 512, rows: str = "list"):
         """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text.  ``rows="numpy"``
         returns the rows as float32 numpy views instead (a list of 768-arrays): turning 768 floats per text into Python
-        floats and back into an array at the store costs as much as the GPU forward (measured 0.26 s + 0.5 s per 20 k texts)."""
+        floats and back into an array at the store costs as much as the GPU forward (measured 0.26 s + 0.5 s per 20 k texts).
+
+        With the native tokenizer large calls run as a three-stage pipeline over chunks of ``PIPELINE_CHUNK`` texts: the C++
+        tokenizer (its own threads, GIL released) works on chunk i+1 and the float-list conversion on chunk i-1 while the GPU
+        runs chunk i; results come back through a side stream into pinned memory.  (Sequentially the host stages were a third
+        of the call: 20 k texts took 1.22 s of which the forward 0.8.)"""
         if not texts:
             return []
-        if hasattr(self.tok, "encode_bodies"):
-            body_ids, body_lens = self.tok.encode_bodies(list(texts), max_body=max_length - 4)
-            out = self.embed_bodies(body_ids, body_lens, max_length).cpu().numpy()
-        else:
+        texts = list(texts)
+        if not hasattr(self.tok, "encode_bodies"):
             out = self.embed_ids([wrap_encoder_only(self.tok, t, max_length) for t in texts]).cpu().numpy()
-        return list(out) if rows == "numpy" else out.tolist()
+            return list(out) if rows == "numpy" else out.tolist()
+        torch = self._torch
+        ffi.use_device(self.device.index)
+        C = self.PIPELINE_CHUNK
+        if len(texts) <= C:
+            body_ids, body_lens = self.tok.encode_bodies(texts, max_body=max_length - 4)
+            out = self.embed_bodies(body_ids, body_lens, max_length).cpu().numpy()
+            return list(out) if rows == "numpy" else out.tolist()
+        from concurrent.futures import ThreadPoolExecutor
+        chunks = [texts[i:i + C] for i in range(0, len(texts), C)]
+        main = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        result: list = []
+
+        def drain(item):
+            host, done = item
+            done.synchronize()
+            result.extend(list(host.numpy()) if rows == "numpy" else host.numpy().tolist())
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="hip-tokenize") as ex:
+            fut = ex.submit(self.tok.encode_bodies, chunks[0], max_length - 4)
+            waiting = None
+            for k in range(len(chunks)):
+                body_ids, body_lens = fut.result()
+                if k + 1 < len(chunks):
+                    fut = ex.submit(self.tok.encode_bodies, chunks[k + 1], max_length - 4)
+                dev = self.embed_bodies(body_ids, body_lens, max_length)          # enqueued on the main stream
+                ready = torch.cuda.Event()
+                ready.record(main)
+                host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    host.copy_(dev, non_blocking=True)
+                    dev.record_stream(side)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                if waiting is not None:
+                    drain(waiting)                                                # chunk k-1 -> python floats while the GPU runs chunk k
+                waiting = (host, done)
+            drain(waiting)
+        return result
 
 
 _MODELS: dict = {}

@@ -444,3 +444,42 @@ def test_packed_attention_does_not_touch_its_neighbours(gpu):
             s[:, :, 50] = float("-inf")
         ref = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(n, H * 64)
         _close(torch, out[off[b]:off[b + 1]], ref, rel=2 ** -6, abs_=1.5e-2)
+
+
+def test_embed_texts_pipeline_keeps_order_and_values(gpu, tmp_path):
+    """Large embed_texts calls run as a pipeline (tokenizer thread | GPU | float-list conversion through a side stream and
+    pinned memory): same vectors, same order as one sequential pass (up to what another batch composition changes)."""
+    import glob
+    import json
+    torch, ffi, dev = _env()
+    from safetensors.torch import save_file
+    from tokenizers import ByteLevelBPETokenizer
+    from coderag_amd import encoder as drv
+    d = str(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "code-rag_amd", "*.py")))
+    tr = ByteLevelBPETokenizer(add_prefix_space=False)
+    tr.train(files, vocab_size=2000, min_frequency=2, special_tokens=["<s>", "<pad>", "</s>", "<unk>", "<mask>", "<encoder-only>"])
+    tr.save_model(d)
+    cfg = drv.EncoderConfig(vocab_size=2000, num_layers=2)
+    json.dump({"vocab_size": 2000, "hidden_size": 768, "num_hidden_layers": 2, "num_attention_heads": 12, "intermediate_size": 3072,
+               "max_position_embeddings": 1026, "type_vocab_size": 10}, open(os.path.join(d, "config.json"), "w"))
+    save_file({k: torch.from_numpy(v) for k, v in drv.synthetic_weights(cfg, 5).items()}, os.path.join(d, "model.safetensors"))
+    model = drv.load_unixcoder(d, device=0)
+    src = "".join(open(f, encoding="utf-8").read() for f in files)
+    rng = np.random.default_rng(2)
+    texts = [src[i:i + int(n)] for i, n in zip(rng.integers(0, len(src) - 900, 3500), rng.integers(5, 900, 3500))]
+    model.PIPELINE_CHUNK = 1 << 30
+    want = np.asarray(model.embed_texts(texts), np.float32)
+    model.PIPELINE_CHUNK = 1000
+    try:
+        got_list = model.embed_texts(texts)
+        got_np = model.embed_texts(texts, rows="numpy")
+    finally:
+        model.PIPELINE_CHUNK = type(model).PIPELINE_CHUNK
+    assert len(got_list) == 3500 and isinstance(got_list[0], list) and isinstance(got_list[0][0], float) and len(got_list[0]) == 768
+    got = np.asarray(got_list, np.float32)
+    assert np.array_equal(got, np.stack(got_np))
+    assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos.min() >= 0.9999, cos.min()
