@@ -283,52 +283,95 @@ class HipUniXcoder:
         if lo < 0 or hi >= self.cfg.vocab_size:
             raise ValueError(f"token id {hi if hi >= self.cfg.vocab_size else lo} outside the embedding table (vocab_size {self.cfg.vocab_size})")
 
+    def _pinned(self, slot: int, name: str, n: int, dtype):
+        """A cached pinned host buffer of at least n elements (pinning is slow; calls pack into the same few buffers).  Two
+        slots alternate, each guarded by the event recorded behind the copies that last read it."""
+        torch = self._torch
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        buf = cache.get((slot, name))
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty((max(n, 1 << 16),), dtype=dtype, pin_memory=True)
+            cache[(slot, name)] = buf
+        return buf[:n]
+
+    def _embed_packed(self, batches, lens, fill, n: int):
+        """Run packed batches.  ``batches``: [(rows, Lmax)] from plan_batches(packed=True); ``lens[i]``: tokens of input row i;
+        ``fill(i, dst)``: write row i's ids into the int32 numpy view ``dst``.  Everything the device needs from the host -- the
+        ids of ALL batches back to back, their row offsets, the scatter order -- goes up in THREE asynchronous copies from
+        pinned memory before the first kernel, so the host never waits on the stream while it enqueues (a pageable copy per
+        batch kept the host in lockstep with the GPU, and nothing else could overlap with it).  Returns f32 CUDA [n, 768]."""
+        torch = self._torch
+        ffi.use_device(self.device.index)
+        total = int(sum(int(lens[i]) for rows, _ in batches for i in rows))
+        nrows = sum(len(rows) for rows, _ in batches)
+        st = self.__dict__.setdefault("_pin_state", {"slot": 0, "events": [None, None]})
+        slot = st["slot"] = st["slot"] ^ 1
+        if st["events"][slot] is not None:
+            st["events"][slot].synchronize()          # the copies that last read this slot's buffers have run
+        p_ids = self._pinned(slot, "ids", total, torch.int32)
+        p_off = self._pinned(slot, "off", nrows + len(batches), torch.int32)
+        p_ord = self._pinned(slot, "ord", nrows, torch.int64)
+        h_ids, h_off, h_ord = p_ids.numpy(), p_off.numpy(), p_ord.numpy()
+        spans, t0, o0, r0 = [], 0, 0, 0
+        for rows, Lmax in batches:
+            pos = 0
+            h_off[o0] = 0
+            for r, i in enumerate(rows):
+                ln = int(lens[i])
+                fill(i, h_ids[t0 + pos:t0 + pos + ln])
+                pos += ln
+                h_off[o0 + r + 1] = pos
+            h_ord[r0:r0 + len(rows)] = rows
+            spans.append((t0, pos, o0, len(rows), r0, Lmax))
+            t0, o0, r0 = t0 + pos, o0 + len(rows) + 1, r0 + len(rows)
+        d_ids = p_ids.to(self.device, non_blocking=True)
+        d_off = p_off.to(self.device, non_blocking=True)
+        d_ord = p_ord.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        st["events"][slot] = ev
+        if n == 1:                         # the query path: no scatter through a device index
+            return self.forward_packed(d_ids, d_off, spans[0][5])
+        out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        for t0, nt, o0, nr, r0, Lmax in spans:
+            out[d_ord[r0:r0 + nr]] = self.forward_packed(d_ids[t0:t0 + nt], d_off[o0:o0 + nr + 1], Lmax)
+        return out
+
     def embed_ids(self, id_lists, max_tokens: int = 65536):
         """list of token-id lists (each <= 512) -> f32 CUDA tensor [n, 768] in input order."""
-        torch = self._torch
         n = len(id_lists)
         for x in id_lists:
-            if len(x) and (min(x) < 0 or max(x) >= self.cfg.vocab_size):
+            if len(x) == 0:
+                raise ValueError("an empty token list cannot be embedded (the reference's tokenize() always emits 4 specials)")
+            if min(x) < 0 or max(x) >= self.cfg.vocab_size:
                 raise ValueError(f"token id outside the embedding table (vocab_size {self.cfg.vocab_size})")
             if len(x) > self.cfg.max_position_embeddings - 2:
                 raise ValueError(f"{len(x)} tokens exceed the position table ({self.cfg.max_position_embeddings - 2})")
-        out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        if any(len(x) == 0 for x in id_lists):
-            raise ValueError("an empty token list cannot be embedded (the reference's tokenize() always emits 4 specials)")
-        for rows, _ in self.plan_batches([len(x) for x in id_lists], max_tokens, max_rows=4096, packed=True):
-            flat, off, Lmax = self.pack_rows(id_lists, rows)
-            res = self.forward_packed(torch.from_numpy(flat).to(self.device), torch.from_numpy(off).to(self.device), Lmax)
-            if n == 1:                     # the query path: no scatter through a device index
-                return res
-            out[torch.as_tensor(rows, device=self.device)] = res
-        return out
+        lens = np.fromiter((len(x) for x in id_lists), dtype=np.int64, count=n)
+
+        def fill(i, dst):
+            dst[:] = id_lists[i]
+        return self._embed_packed(self.plan_batches(lens, max_tokens, max_rows=4096, packed=True), lens, fill, n)
 
     def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 65536):
         """Batch form of tokenize + wrap + embed for a tokenizer that returns an id matrix (``NativeBpeTokenizer``):
         ``body_ids`` int32 [n, >= max_length - 4], ``body_lens`` the untruncated counts.  Rows are wrapped as
         [<s>, <encoder-only>, </s>] + body[: max_length - 4] + [</s>] (unixcoder_provider.py:105-122) while being packed into
-        the padded batch arrays -- no per-token Python work."""
-        torch, tok = self._torch, self.tok
+        the batch arrays -- no per-token Python work."""
+        tok = self.tok
         n = int(body_lens.shape[0])
         blen = np.minimum(body_lens.astype(np.int64), max_length - 4)
         self._check_ids(body_ids[:, : int(blen.max()) if n else 0], blen)
-        out = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        for rows, _ in self.plan_batches(blen + 4, max_tokens, max_rows=4096, packed=True):
-            lens = blen[rows] + 4
-            off = np.zeros(len(rows) + 1, dtype=np.int32)
-            np.cumsum(lens, out=off[1:])
-            flat = np.empty(int(off[-1]), dtype=np.int32)
-            flat[off[:-1]], flat[off[:-1] + 1], flat[off[:-1] + 2] = tok.cls_id, tok.enc_only_id, tok.sep_id
-            flat[off[1:] - 1] = tok.sep_id
-            for r, i in enumerate(rows):
-                b = int(blen[i])
-                flat[off[r] + 3:off[r] + 3 + b] = body_ids[i, :b]
-            Lmax = (int(lens.max()) + 15) // 16 * 16
-            res = self.forward_packed(torch.from_numpy(flat).to(self.device), torch.from_numpy(off).to(self.device), Lmax)
-            if n == 1:
-                return res
-            out[torch.as_tensor(rows, device=self.device)] = res
-        return out
+        head = np.asarray([tok.cls_id, tok.enc_only_id, tok.sep_id], dtype=np.int32)
+        sep = tok.sep_id
+
+        def fill(i, dst):
+            b = int(blen[i])
+            dst[:3] = head
+            dst[3:3 + b] = body_ids[i, :b]
+            dst[3 + b] = sep
+        lens = blen + 4
+        return self._embed_packed(self.plan_batches(lens, max_tokens, max_rows=4096, packed=True), lens, fill, n)
 
     PIPELINE_CHUNK = 4096      # texts per stage of the text pipeline below
 
