@@ -296,7 +296,8 @@ class HipUniXcoder:
 
     def _embed_packed(self, batches, lens, fill, n: int):
         """Run packed batches.  ``batches``: [(rows, Lmax)] from plan_batches(packed=True); ``lens[i]``: tokens of input row i;
-        ``fill(i, dst)``: write row i's ids into the int32 numpy view ``dst``.  Everything the device needs from the host -- the
+        ``fill(rows, row_lens, dst, starts)``: write the ids of a batch's rows back to back into the int32 numpy view ``dst``
+        (row r begins at ``starts[r]``).  Everything the device needs from the host -- the
         ids of ALL batches back to back, their row offsets, the scatter order -- goes up in THREE asynchronous copies from
         pinned memory before the first kernel, so the host never waits on the stream while it enqueues (a pageable copy per
         batch kept the host in lockstep with the GPU, and nothing else could overlap with it).  Returns f32 CUDA [n, 768]."""
@@ -314,13 +315,11 @@ class HipUniXcoder:
         h_ids, h_off, h_ord = p_ids.numpy(), p_off.numpy(), p_ord.numpy()
         spans, t0, o0, r0 = [], 0, 0, 0
         for rows, Lmax in batches:
-            pos = 0
+            bl = np.asarray(lens)[rows]
             h_off[o0] = 0
-            for r, i in enumerate(rows):
-                ln = int(lens[i])
-                fill(i, h_ids[t0 + pos:t0 + pos + ln])
-                pos += ln
-                h_off[o0 + r + 1] = pos
+            np.cumsum(bl, out=h_off[o0 + 1:o0 + 1 + len(rows)])
+            pos = int(h_off[o0 + len(rows)])
+            fill(rows, bl, h_ids[t0:t0 + pos], h_off[o0:o0 + len(rows)])
             h_ord[r0:r0 + len(rows)] = rows
             spans.append((t0, pos, o0, len(rows), r0, Lmax))
             t0, o0, r0 = t0 + pos, o0 + len(rows) + 1, r0 + len(rows)
@@ -349,8 +348,9 @@ class HipUniXcoder:
                 raise ValueError(f"{len(x)} tokens exceed the position table ({self.cfg.max_position_embeddings - 2})")
         lens = np.fromiter((len(x) for x in id_lists), dtype=np.int64, count=n)
 
-        def fill(i, dst):
-            dst[:] = id_lists[i]
+        def fill(rows, row_lens, dst, starts):
+            for r, i in enumerate(rows):
+                dst[starts[r]:starts[r] + row_lens[r]] = id_lists[i]
         return self._embed_packed(self.plan_batches(lens, max_tokens, max_rows=4096, packed=True), lens, fill, n)
 
     def embed_bodies(self, body_ids: np.ndarray, body_lens: np.ndarray, max_length: int = 512, max_tokens: int = 65536):
@@ -365,15 +365,18 @@ class HipUniXcoder:
         head = np.asarray([tok.cls_id, tok.enc_only_id, tok.sep_id], dtype=np.int32)
         sep = tok.sep_id
 
-        def fill(i, dst):
-            b = int(blen[i])
-            dst[:3] = head
-            dst[3:3 + b] = body_ids[i, :b]
-            dst[3 + b] = sep
+        def fill(rows, row_lens, dst, starts):      # whole batch at once: [specials | body | </s>] rows, then the valid cells in order
+            b = row_lens - 4
+            width = int(b.max()) + 4
+            arr = np.empty((len(rows), width), dtype=np.int32)
+            arr[:, :3] = head
+            arr[:, 3:width - 1] = body_ids[rows, : width - 4]
+            arr[np.arange(len(rows)), 3 + b] = sep
+            dst[:] = arr[np.arange(width)[None, :] < row_lens[:, None]]
         lens = blen + 4
         return self._embed_packed(self.plan_batches(lens, max_tokens, max_rows=4096, packed=True), lens, fill, n)
 
-    PIPELINE_CHUNK = 4096      # texts per stage of the text pipeline below
+    PIPELINE_CHUNK = 8192      # texts per stage of the text pipeline below
 
     def embed_texts(self, texts, max_length: int = 512, rows: str = "list"):
         """``embed_batch_sync`` (unixcoder_provider.py:195-215): one 768-vector of python floats per text.  ``rows="numpy"``
