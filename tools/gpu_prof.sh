@@ -10,7 +10,7 @@ echo "=== kernel trace"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py "$@" --no-cpu-baseline --check-rows 0 > "$out/trace.log" 2>&1
 rc=$?; echo "rc=$rc"; tail -n 3 "$out/trace.log"
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" ; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" ; do
   name=$(echo $pmc | tr ' ' '_')
   echo "=== pmc $pmc"
   timeout -k 10 500 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc_$name" -- python3 bench.py "$@" --no-cpu-baseline --check-rows 0 > "$out/pmc_$name.log" 2>&1

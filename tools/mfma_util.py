@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-L = ["# MFMA utilisation (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; bench.py --rows 10000000 --embed-chunks 6000)", "",
+L = ["# MFMA utilisation (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; bench.py through tools/gpu_prof.sh; the run's arguments are in profiles/README.md)", "",
      "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs); means over the kernel's dispatches", "",
      "| kernel | dispatches | kernel cycles | MFMA busy cycles | MFMA utilisation |", "|---|---|---|---|---|"]
 for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
