@@ -48,6 +48,7 @@ struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     bool use_ring = false;  // <= 64 queries: k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs) instead of k_scan
+    int spare_cus = 0;     // CUs the main scans leave to the small kernels of the other lane (overlapped searches)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
@@ -59,14 +60,34 @@ struct crh_index {
     // tuning
     int seed_tiles = 4096, wave_cap = 2048, qcap = 65536, force_fallback = 0;
 
-    // workspace (lazily sized)
-    int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
-    int64_t ws_mask_tiles = 0;
-    float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
-    u32x4 *qfrag = nullptr, *wave_lists = nullptr;
-    uint32_t *effmask = nullptr;
-    u32x2 *qlist = nullptr;
-    unsigned long long *skeys = nullptr;
+    // search workspace: LANES (lazily sized; lane 0 is the one serial searches use).  Everything a batch writes between its query
+    // preparation and its final selection lives in one lane, so several batches may be in flight at once.  With overlap on,
+    // consecutive batches take the lanes in turn: a lane's own stream carries the batch's head (query preparation, seed scan,
+    // threshold) and its selection, ONE stream shared by all lanes carries the main scans, back to back in batch order.  The
+    // small kernels cannot run while a main scan fills the GPU; they run in the gap that opens when the next scan's head is not
+    // ready yet -- once every nlanes-1 scans, the heads and selections of nlanes-1 batches side by side (a selection alone fills
+    // 64 CUs for ~60 us, a seed scan is bandwidth-bound at ~40 us): per batch ~ seed + (selection + preparation + threshold) /
+    // (nlanes-1) instead of their sum.
+    struct Lane {
+        int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
+        int64_t ws_mask_tiles = 0;
+        float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
+        u32x4 *qfrag = nullptr, *wave_lists = nullptr;
+        uint32_t *effmask = nullptr;
+        u32x2 *qlist = nullptr;
+        unsigned long long *skeys = nullptr;
+        hipStream_t st = nullptr;                 // overlap only: the lane's own stream, forked from / joined to the caller's
+        hipEvent_t fork = nullptr, done = nullptr, head_done = nullptr, scan_done = nullptr;
+        bool in_flight = false;                   // work enqueued on `st` that the caller's stream has not been joined to
+        int64_t seq = 0;                          // number of the last batch enqueued here (crh_index::batch_seq)
+    };
+    static constexpr int kLanes = 8;   // at most; `nlanes` of them are in use
+    Lane lane[kLanes];
+    int nlanes = 4;
+    bool overlap = false;
+    hipStream_t scan_st = nullptr;   // overlap only: every main scan, in batch order
+    int next_lane = 0;
+    int64_t batch_seq = 0;
     SearchStatus *status = nullptr;
     float *stage_q = nullptr;
     int64_t stage_q_elems = 0;
@@ -129,52 +150,72 @@ int ensure_stage_in(crh_index *h, int64_t bytes)
 int scan_blocks(const crh_index *h, int64_t nitems)
 {
     int64_t b = ceil_div(nitems, kWaves);
-    if (b > h->cu_count) b = h->cu_count;
+    if (b > h->cu_count - h->spare_cus) b = h->cu_count - h->spare_cus;
     if (b < 1) b = 1;
     return (int)b;
 }
 
-// (re)allocate the search workspace for the current tuning
-int ensure_workspace(crh_index *h, int wave_cap, int qcap)
+// (re)allocate one lane of the search workspace for the given candidate capacities
+int ensure_workspace(crh_index *h, crh_index::Lane &w, int wave_cap, int qcap)
 {
     const int blocks = h->cu_count;
-    if (!h->qn) CRH_TRY(dev_alloc(&h->qn, (int64_t)kWideQ * h->dim));
-    if (!h->qfrag) CRH_TRY(dev_alloc(&h->qfrag, (int64_t)(kWideQ / 32) * h->ksteps * 64));
-    if (!h->tau) CRH_TRY(dev_alloc(&h->tau, kWideQ));
+    if (!w.qn) CRH_TRY(dev_alloc(&w.qn, (int64_t)kWideQ * h->dim));
+    if (!w.qfrag) CRH_TRY(dev_alloc(&w.qfrag, (int64_t)(kWideQ / 32) * h->ksteps * 64));
+    if (!w.tau) CRH_TRY(dev_alloc(&w.tau, kWideQ));
     if (!h->status) {
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
         CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
     }
-    if (h->ws_seed < h->seed_tiles) {
-        dev_free(h->gmax);
-        h->ws_seed = 0;
-        CRH_TRY(dev_alloc(&h->gmax, (int64_t)h->seed_tiles * kWideQ));
-        h->ws_seed = h->seed_tiles;
+    if (w.ws_seed < h->seed_tiles) {
+        dev_free(w.gmax);
+        w.ws_seed = 0;
+        CRH_TRY(dev_alloc(&w.gmax, (int64_t)h->seed_tiles * kWideQ));
+        w.ws_seed = h->seed_tiles;
     }
-    if (h->ws_mask_tiles < h->cap_tiles) {
-        dev_free(h->effmask);
-        h->ws_mask_tiles = 0;
-        CRH_TRY(dev_alloc(&h->effmask, h->cap_tiles));
-        h->ws_mask_tiles = h->cap_tiles;
+    if (w.ws_mask_tiles < h->cap_tiles) {
+        dev_free(w.effmask);
+        w.ws_mask_tiles = 0;
+        CRH_TRY(dev_alloc(&w.effmask, h->cap_tiles));
+        w.ws_mask_tiles = h->cap_tiles;
     }
-    if (h->ws_blocks != blocks || h->ws_wave_cap != wave_cap) {
+    if (w.ws_blocks != blocks || w.ws_wave_cap != wave_cap) {
         const int64_t bytes = (int64_t)blocks * kWaves * wave_cap * 16;
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "candidate workspace of %lld bytes exceeds the budget", (long long)bytes);
-        dev_free(h->wave_lists);
-        h->ws_blocks = h->ws_wave_cap = 0;
-        CRH_TRY(dev_alloc(&h->wave_lists, (int64_t)blocks * kWaves * wave_cap));
-        h->ws_blocks = blocks;
-        h->ws_wave_cap = wave_cap;
+        dev_free(w.wave_lists);
+        w.ws_blocks = w.ws_wave_cap = 0;
+        CRH_TRY(dev_alloc(&w.wave_lists, (int64_t)blocks * kWaves * wave_cap));
+        w.ws_blocks = blocks;
+        w.ws_wave_cap = wave_cap;
     }
-    if (h->ws_qcap != qcap) {
+    if (w.ws_qcap != qcap) {
         const int64_t bytes = (int64_t)kWideQ * qcap * 16;
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "per-query candidate lists of %lld bytes exceed the budget", (long long)bytes);
-        dev_free(h->qlist);
-        dev_free(h->skeys);
-        h->ws_qcap = 0;
-        CRH_TRY(dev_alloc(&h->qlist, (int64_t)kWideQ * qcap));
-        CRH_TRY(dev_alloc(&h->skeys, (int64_t)kWideQ * qcap));
-        h->ws_qcap = qcap;
+        dev_free(w.qlist);
+        dev_free(w.skeys);
+        w.ws_qcap = 0;
+        CRH_TRY(dev_alloc(&w.qlist, (int64_t)kWideQ * qcap));
+        CRH_TRY(dev_alloc(&w.skeys, (int64_t)kWideQ * qcap));
+        w.ws_qcap = qcap;
+    }
+    return CRH_OK;
+}
+// lane 0 at the current tuning: what the entry points outside crh_search work in
+int ensure_workspace0(crh_index *h)
+{
+    crh_index::Lane &w = h->lane[0];
+    return ensure_workspace(h, w, std::max(h->wave_cap, w.ws_wave_cap), std::max(h->qcap, w.ws_qcap));
+}
+
+// Make `st` wait for everything the lanes still have in flight (no host synchronisation).  Every entry point that reads or
+// writes what a search reads -- and the end of every search that is not left overlapped -- passes through here.
+int join_lanes(crh_index *h, hipStream_t st, int keep_last = 0)
+{
+    for (int l = 0; l < crh_index::kLanes; ++l) {
+        crh_index::Lane &w = h->lane[l];
+        if (w.in_flight && w.seq <= h->batch_seq - keep_last) {
+            CRH_HIP(hipStreamWaitEvent(st, w.done, 0));
+            w.in_flight = false;
+        }
     }
     return CRH_OK;
 }
@@ -188,7 +229,7 @@ __global__ void k_fill_pad(float *s, int64_t *r, int64_t n)
     }
 }
 
-int build_mask(crh_index *h, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
+int build_mask(crh_index *h, crh_index::Lane &w, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
 {
     if (nfilt == 0) {
         *mask_out = h->alive;
@@ -204,20 +245,20 @@ int build_mask(crh_index *h, const crh_filter *filters, int nfilt, const uint32_
     }
     const int64_t rows = (h->count + 63) & ~63LL;
     hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, h->alive, h->codes, h->cap_rows,
-                       h->count, fs, h->effmask);
+                       h->count, fs, w.effmask);
     CRH_HIP(hipGetLastError());
-    *mask_out = h->effmask;
+    *mask_out = w.effmask;
     return CRH_OK;
 }
 
 // scan kernel instantiations: k-steps = dim / 16; 64 queries per pass except for dim 1536 (32: LDS)
 template <int MODE>
-int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
+int launch_scan(crh_index *h, crh_index::Lane &w, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
                 SearchStatus *stt)
 {
 #define CRH_SCAN(KS, QB)                                                                                                       \
-    hipLaunchKernelGGL((k_scan<KS, MODE, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, h->qfrag, h->tau, \
-                       mask, nitems, stride, h->gmax, h->wave_lists, wave_cap, stt->qcount, h->qlist, qcap, stt)
+    hipLaunchKernelGGL((k_scan<KS, MODE, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, w.qfrag, w.tau, \
+                       mask, nitems, stride, w.gmax, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_SCAN(24, 2); break;
     case 48: CRH_SCAN(48, 2); break;
@@ -234,13 +275,13 @@ int launch_scan(crh_index *h, int blocks, hipStream_t st, const uint32_t *mask, 
 // (k_scan: 16 waves share them), so the workgroup's share of the candidate workspace is cut into 2 lists of 8 x wave_cap
 constexpr int kRingWaves = 2;
 template <int MODE>
-int launch_scan_ring(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
+int launch_scan_ring(crh_index *h, crh_index::Lane &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
                      SearchStatus *stt)
 {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
 #define CRH_RING(KS)                                                                                                               \
-    hipLaunchKernelGGL((k_scan_ring<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
-                       h->gmax, h->wave_lists, kRingWaves, wave_cap * (kWaves / kRingWaves), stt->qcount, h->qlist, qcap, stt)
+    hipLaunchKernelGGL((k_scan_ring<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, w.qfrag, w.tau, mask, nitems, stride, nblk, \
+                       w.gmax, w.wave_lists, kRingWaves, wave_cap * (kWaves / kRingWaves), stt->qcount, w.qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_RING(24); break;
     case 48: CRH_RING(48); break;
@@ -255,13 +296,13 @@ int launch_scan_ring(crh_index *h, hipStream_t st, const uint32_t *mask, int nit
 
 // the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
 template <int MODE>
-int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
+int launch_scan_wide(crh_index *h, crh_index::Lane &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
                      SearchStatus *stt)
 {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
 #define CRH_WIDE(KS)                                                                                                              \
-    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(512), 0, st, h->xt, h->qfrag, h->tau, mask, nitems, stride, nblk, \
-                       h->gmax, kWideQ, h->wave_lists, kWideWaves, wave_cap * (kWaves / kWideWaves), stt->qcount, h->qlist, qcap, stt)
+    hipLaunchKernelGGL((k_scan_wide<KS, MODE>), dim3(blocks), dim3(512), 0, st, h->xt, w.qfrag, w.tau, mask, nitems, stride, nblk, \
+                       w.gmax, kWideQ, w.wave_lists, kWideWaves, wave_cap * (kWaves / kWideWaves), stt->qcount, w.qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_WIDE(24); break;
     case 48: CRH_WIDE(48); break;
@@ -273,9 +314,12 @@ int launch_scan_wide(crh_index *h, hipStream_t st, const uint32_t *mask, int nit
 }
 
 // one batch (<= batch_q queries through k_scan, or up to kWideQ through k_scan_wide), everything enqueued on `st`
-int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
-                  int64_t *out_r, int slot, hipStream_t st)
+int enqueue_batch(crh_index *h, crh_index::Lane &w, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
+                  int64_t *out_r, int slot, hipStream_t st, hipStream_t scan_st = nullptr)
 {
+    // scan_st (overlapped searches): the stream every main scan of the index runs on, one after the other -- `st` then carries only
+    // this batch's head (query preparation, seed scan, threshold) and its selection, tied to the scan by the lane's two events
+    const bool split = scan_st != nullptr && scan_st != st;
     const int64_t ntiles = ceil_div(h->count, kTileRows);
     if (ntiles == 0) {
         CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
@@ -284,7 +328,7 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     }
-    const int wave_cap = h->ws_wave_cap, qcap = h->ws_qcap;
+    const int wave_cap = w.ws_wave_cap, qcap = w.ws_qcap;
     const float margin = margin_for(h);
     SearchStatus *stt = h->status + slot;
     const bool wide = nq > h->batch_q;
@@ -294,35 +338,44 @@ int enqueue_batch(crh_index *h, const float *q_dev, int nq, int k, const uint32_
     const int qstride = wide ? kWideQ : 64;                // row pitch of the seed maxima
 
     if (h->dtype == CRH_DTYPE_BF16)
-        hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
     else
-        hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, h->qn, h->qfrag, stt);
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
     CRH_HIP(hipGetLastError());
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     const bool ring = !wide && h->use_ring;
     if (wide)
-        CRH_TRY(launch_scan_wide<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
+        CRH_TRY(launch_scan_wide<0>(h, w, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else if (ring)
-        CRH_TRY(launch_scan_ring<0>(h, st, mask, G, stride, nblk, wave_cap, qcap, stt));
+        CRH_TRY(launch_scan_ring<0>(h, w, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else
-        CRH_TRY(launch_scan<0>(h, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
-    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, h->gmax, G, k, margin, nq, h->tau, qstride);
+        CRH_TRY(launch_scan<0>(h, w, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
+    hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, w.gmax, G, k, margin, nq, w.tau, qstride);
     CRH_HIP(hipGetLastError());
-    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
+    hipStream_t ss = split ? scan_st : st;
+    if (split) {
+        CRH_HIP(hipEventRecord(w.head_done, st));
+        CRH_HIP(hipStreamWaitEvent(ss, w.head_done, 0));
+    }
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], ss));
     if (wide)
-        CRH_TRY(launch_scan_wide<1>(h, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
+        CRH_TRY(launch_scan_wide<1>(h, w, ss, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
     else if (ring)
-        CRH_TRY(launch_scan_ring<1>(h, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
+        CRH_TRY(launch_scan_ring<1>(h, w, ss, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
     else
-        CRH_TRY(launch_scan<1>(h, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
-    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
+        CRH_TRY(launch_scan<1>(h, w, scan_blocks(h, ntiles), ss, mask, (int)ntiles, 1, wave_cap, qcap, stt));
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], ss));
+    if (split) {
+        CRH_HIP(hipEventRecord(w.scan_done, ss));
+        CRH_HIP(hipStreamWaitEvent(st, w.scan_done, 0));
+    }
     if (h->dtype == CRH_DTYPE_F32)
-        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, h->qlist, stt->qcount, qcap, h->skeys, h->qn, h->xt,
+        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     else
-        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, h->qlist, stt->qcount, qcap, h->skeys, h->qn, h->xt,
+        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     CRH_HIP(hipGetLastError());
     h->stats.rows += h->count;
@@ -341,6 +394,7 @@ int next_pow2(int64_t v)
 
 int finish_pending(crh_index *h, hipStream_t st)
 {
+    CRH_TRY(join_lanes(h, st));
     if (h->pending.empty()) return CRH_OK;
     CRH_HIP(hipStreamSynchronize(st));
     const int used = std::max(1, std::min(h->next_slot, kStatusSlots));   // slots are handed out in order from 0
@@ -349,6 +403,7 @@ int finish_pending(crh_index *h, hipStream_t st)
     std::vector<Pending> todo;
     todo.swap(h->pending);
     h->next_slot = 0;
+    crh_index::Lane &w = h->lane[0];   // (everything is idle: a batch that overflowed is re-run alone, in lane 0, on `st`)
     for (const Pending &p : todo) {
         SearchStatus s = host[p.slot];
         if (h->profiling && h->count > 0) {
@@ -362,12 +417,12 @@ int finish_pending(crh_index *h, hipStream_t st)
         while (s.wave_overflow || s.q_overflow) {
             if (++attempts > 4) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
             h->stats.fallback_used = 1;
-            const int wc = std::max(h->ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
-            const int qc = std::max(h->ws_qcap, next_pow2((int64_t)s.max_qcount));
-            CRH_TRY(ensure_workspace(h, wc, qc));
+            const int wc = std::max(w.ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
+            const int qc = std::max(w.ws_qcap, next_pow2((int64_t)s.max_qcount));
+            CRH_TRY(ensure_workspace(h, w, wc, qc));
             const uint32_t *mask = nullptr;
-            CRH_TRY(build_mask(h, p.filt, p.nfilt, &mask, st));
-            CRH_TRY(enqueue_batch(h, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st));
+            CRH_TRY(build_mask(h, w, p.filt, p.nfilt, &mask, st));
+            CRH_TRY(enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st));
             CRH_HIP(hipStreamSynchronize(st));
             CRH_HIP(hipMemcpy(&s, h->status, sizeof(SearchStatus), hipMemcpyDeviceToHost));
         }
@@ -444,6 +499,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     h->ncols = n_code_cols;
     h->device = device;
     h->cu_count = prop.multiProcessorCount;
+    if (const char *e = getenv("CODERAG_HIP_SPARE_CUS")) h->spare_cus = std::max(0, std::min(atoi(e), h->cu_count - 8));
     h->cap_rows = (capacity_rows + 31) & ~31LL;
     h->cap_tiles = h->cap_rows / 32;
     int rc = dev_alloc(&h->xt, h->cap_tiles * h->ksteps * 64);
@@ -473,14 +529,22 @@ int crh_index_destroy(crh_index *h)
     dev_free(h->alive);
     dev_free(h->codes);
     dev_free(h->scratch_u32);
-    dev_free(h->qn);
-    dev_free(h->gmax);
-    dev_free(h->tau);
-    dev_free(h->qfrag);
-    dev_free(h->wave_lists);
-    dev_free(h->effmask);
-    dev_free(h->qlist);
-    dev_free(h->skeys);
+    for (auto &w : h->lane) {
+        dev_free(w.qn);
+        dev_free(w.gmax);
+        dev_free(w.tau);
+        dev_free(w.qfrag);
+        dev_free(w.wave_lists);
+        dev_free(w.effmask);
+        dev_free(w.qlist);
+        dev_free(w.skeys);
+        if (w.fork) (void)hipEventDestroy(w.fork);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.head_done) (void)hipEventDestroy(w.head_done);
+        if (w.scan_done) (void)hipEventDestroy(w.scan_done);
+        if (w.st) (void)hipStreamDestroy(w.st);
+    }
+    if (h->scan_st) (void)hipStreamDestroy(h->scan_st);
     dev_free(h->status);
     dev_free(h->stage_q);
     dev_free(h->stage_os);
@@ -520,6 +584,7 @@ static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device
                     (long long)h->cap_rows);
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CRH_TRY(join_lanes(h, st));   // overlapped searches still in flight read the last tile and its alive word
     const int64_t chunk = 65536;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
@@ -564,6 +629,7 @@ int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows)
     if (n <= 0) return CRH_OK;
     if (!rows) return fail(CRH_E_INVALID, "rows is NULL");
     DeviceGuard g(h->device);
+    CRH_TRY(join_lanes(h, nullptr));
     CRH_TRY(ensure_stage_in(h, n * 8));
     CRH_HIP(hipMemcpy(h->stage_in, rows, (size_t)n * 8, hipMemcpyHostToDevice));
     CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
@@ -585,9 +651,9 @@ int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_fi
     if (h->count == 0) return CRH_OK;
     DeviceGuard g(h->device);
     CRH_HIP(hipDeviceSynchronize());   // searches in flight on other streams read `alive` / the shared mask buffer
-    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    CRH_TRY(ensure_workspace0(h));
     const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, filters, n_filters, &mask, nullptr));
+    CRH_TRY(build_mask(h, h->lane[0], filters, n_filters, &mask, nullptr));
     const int64_t ntiles = ceil_div(h->count, 32);
     CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
     hipLaunchKernelGGL(k_tombstone_mask, dim3((unsigned)ceil_div(ntiles, 256)), dim3(256), 0, 0, h->alive, mask, ntiles, h->scratch_u32);
@@ -764,10 +830,12 @@ int crh_debug_read_ceiling(crh_index *h, void *stream)
     DeviceGuard g(h->device);
     const int64_t ntiles = ceil_div(h->count, kTileRows);
     if (ntiles == 0) return CRH_OK;
-    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    CRH_TRY(join_lanes(h, static_cast<hipStream_t>(stream)));
+    CRH_TRY(ensure_workspace0(h));
+    crh_index::Lane &w = h->lane[0];
     const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
-    return launch_scan<2>(h, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, h->ws_wave_cap, h->ws_qcap, h->status);
+    CRH_TRY(build_mask(h, w, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
+    return launch_scan<2>(h, w, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, w.ws_wave_cap, w.ws_qcap, h->status);
 }
 #endif  // CRH_ENABLE_DEBUG
 
@@ -795,9 +863,12 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     // force_fallback (testing): start from absurdly small candidate buffers so the regrow-and-rerun path runs
-    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->ws_wave_cap);
-    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->ws_qcap);
-    CRH_TRY(ensure_workspace(h, wc, qc));
+    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->lane[0].ws_wave_cap);
+    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->lane[0].ws_qcap);
+    // overlapped: device-resident queries and outputs only (a host buffer is read / filled synchronously, below)
+    const bool overlapped = h->overlap && queries_on_device && out_on_device;
+    if (!overlapped) CRH_TRY(join_lanes(h, st));
+    CRH_TRY(ensure_workspace(h, h->lane[0], wc, qc));
 
     const float *q_dev = queries;
     if (!queries_on_device) {
@@ -828,13 +899,30 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     }
     if (h->pending.empty()) h->stats = crh_search_stats{};
 
-    const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, filters, n_filters, &mask, st));
     // more than one k_scan pass worth of queries: up to kWideQ of them share ONE corpus pass through k_scan_wide
     for (int q0 = 0, b = 0; q0 < nq; q0 += b) {
         const int left = nq - q0;
         b = (h->wide_ok && left > h->batch_q) ? std::min(kWideQ, left) : std::min(h->batch_q, left);
         if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
+        // the lane of this batch and the stream it runs on: serial = lane 0 on the caller's stream; overlapped = the lanes in
+        // turn, each on its own stream, entered through an event recorded on the caller's stream at this call (what the caller
+        // enqueued before the call -- the queries -- is complete before the lane reads it) and left through the lane's `done`
+        // event, which the caller's stream waits for in crh_search_finish or the next entry point that is not an overlapped search
+        crh_index::Lane &w = h->lane[overlapped ? h->next_lane : 0];
+        hipStream_t run = st;
+        if (overlapped) {
+            h->next_lane = (h->next_lane + 1) % h->nlanes;
+            if (!w.st) {
+                CRH_HIP(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+                CRH_HIP(hipEventCreateWithFlags(&w.fork, hipEventDisableTiming));
+                CRH_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+                CRH_HIP(hipEventCreateWithFlags(&w.head_done, hipEventDisableTiming));
+                CRH_HIP(hipEventCreateWithFlags(&w.scan_done, hipEventDisableTiming));
+                if (!h->scan_st) CRH_HIP(hipStreamCreateWithFlags(&h->scan_st, hipStreamNonBlocking));
+            }
+            CRH_TRY(ensure_workspace(h, w, wc, qc));
+            run = w.st;
+        }
         Pending p{};
         p.nq = b;
         p.k = k;
@@ -845,10 +933,20 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         p.out_s = os + (int64_t)q0 * k;
         p.out_r = orow + (int64_t)q0 * k;
         p.slot = h->next_slot++;
-        CRH_TRY(enqueue_batch(h, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
+        const uint32_t *mask = nullptr;
+        if (overlapped) {
+            CRH_HIP(hipEventRecord(w.fork, st));
+            CRH_HIP(hipStreamWaitEvent(run, w.fork, 0));
+        }
+        // (a filter mask lives in the lane: the lane's stream orders its rebuild after the lane's previous scan)
+        CRH_TRY(build_mask(h, w, filters, n_filters, &mask, run));
+        CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, run, overlapped ? h->scan_st : nullptr));
+        if (overlapped) {
+            CRH_HIP(hipEventRecord(w.done, run));
+            w.in_flight = true;
+            w.seq = ++h->batch_seq;
+        }
         h->pending.push_back(p);
-        // a filtered search whose mask lives in the shared effmask buffer must complete before the next call
-        // rebuilds that buffer; the stream orders that for us.
     }
     if (!out_on_device || !queries_on_device) {
         CRH_TRY(finish_pending(h, st));
@@ -857,6 +955,24 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
             CRH_HIP(hipMemcpy(out_rows, h->stage_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
         }
     }
+    return CRH_OK;
+}
+
+int crh_search_join(crh_index *h, void *stream, int keep_last)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    return join_lanes(h, static_cast<hipStream_t>(stream), keep_last < 0 ? 0 : keep_last);
+}
+
+int crh_index_set_overlap(crh_index *h, int enable, void *stream)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    DeviceGuard g(h->device);
+    CRH_TRY(join_lanes(h, static_cast<hipStream_t>(stream)));
+    h->overlap = enable != 0;
+    h->nlanes = enable <= 1 ? 4 : std::min(enable, (int)crh_index::kLanes);   // 1 = the default depth
+    h->next_lane = 0;
     return CRH_OK;
 }
 
@@ -931,9 +1047,10 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
     if (limit <= 0 || h->count == 0) return CRH_OK;   // (rows_out_host == NULL: count only, up to `limit`)
     if (n_filters < 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 0..%d", n_filters, CRH_MAX_FILTERS);
     DeviceGuard g(h->device);
-    CRH_TRY(ensure_workspace(h, std::max(h->wave_cap, h->ws_wave_cap), std::max(h->qcap, h->ws_qcap)));
+    CRH_TRY(join_lanes(h, nullptr));
+    CRH_TRY(ensure_workspace0(h));
     const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, filters, n_filters, &mask, nullptr));
+    CRH_TRY(build_mask(h, h->lane[0], filters, n_filters, &mask, nullptr));
     const int64_t ntiles = ceil_div(h->count, 32);
     std::vector<uint32_t> hm((size_t)ntiles);
     CRH_HIP(hipMemcpy(hm.data(), mask, (size_t)ntiles * 4, hipMemcpyDeviceToHost));

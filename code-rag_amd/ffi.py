@@ -18,6 +18,7 @@ LIB_PATH = Path(os.environ.get("CODERAG_HIP_LIB", PKG_DIR / "lib" / "libcoderag_
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NODEVICE, E_INTERNAL = 0, -1, -2, -3, -4, -5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_FILTERS, MAX_K = 8, 1024
+OVERLAP_LANES = 4      # crh_index_set_overlap(enable = 1): batches in flight; a pipelined caller keeps OVERLAP_LANES - 1 ahead
 
 # every symbol include/coderag_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -25,7 +26,7 @@ EXPORTS = (
     "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_append_preprocessed", "crh_index_tombstone",
     "crh_index_tombstone_filter", "crh_index_export", "crh_index_import",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
-    "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
+    "crh_search", "crh_search_finish", "crh_index_set_overlap", "crh_search_join", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
@@ -132,6 +133,8 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_index_read_rows.argtypes = [vp, i64, i64, vp]
     L.crh_search.argtypes = [vp, i32, vp, i32, i32, C.POINTER(Filter), i32, i64, vp, vp, i32, vp]
     L.crh_search_finish.argtypes = [vp, vp]
+    L.crh_index_set_overlap.argtypes = [vp, i32, vp]
+    L.crh_search_join.argtypes = [vp, vp, i32]
     L.crh_search_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
     L.crh_index_set_tuning.argtypes = [vp, i32, i32, i32, i32]
     L.crh_index_set_profiling.argtypes = [vp, i32]
@@ -441,6 +444,17 @@ class Index:
 
     def search_finish(self, stream: int = 0) -> None:
         check(lib().crh_search_finish(self._handle(), stream))
+
+    def set_overlap(self, enable: bool | int, stream: int = 0) -> None:
+        """Overlapped device-to-device searches: consecutive :meth:`search` calls run in internal lanes
+        (``True``: OVERLAP_LANES of them; an int > 1: that many) so the small kernels of several batches run side by side
+        between main scans instead of one after the other.  Outputs are complete only after
+        :meth:`search_finish` (include/coderag_hip.h, crh_index_set_overlap)."""
+        check(lib().crh_index_set_overlap(self._handle(), int(enable), stream))
+
+    def search_join(self, stream: int = 0, keep_last: int = 0) -> None:
+        """Device-side join of the overlapped searches in flight (all, or all but the last ``keep_last`` batches) into ``stream``."""
+        check(lib().crh_search_join(self._handle(), stream, int(keep_last)))
 
     def stats(self) -> dict:
         s = SearchStats()

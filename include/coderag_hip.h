@@ -157,6 +157,22 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
 /* Completes every crh_search enqueued with device outputs since the last finish. */
 int crh_search_finish(crh_index *h, void *stream);
 
+/* Overlapped searches (throughput serving; no reference counterpart -- the reference issues one blocking RPC per query,
+ * embeddings/client.py:142-148).  While enabled, crh_search calls with device-resident queries AND outputs run their batches
+ * in turn in internal lanes (enable = 1: four; enable = n > 1: n, at most 8), each on its own stream, their main scans back to
+ * back on one more: a batch starts after everything the caller had enqueued on
+ * `stream` at the call, but `stream` does NOT wait for it -- so the next batch's query preparation, seed scan and threshold
+ * kernels run beside the previous batch's final selection instead of behind it.  The outputs of ALL such calls are complete,
+ * in `stream` order, only after crh_search_finish(h, stream) (or any other entry point of this index on `stream`, or disabling
+ * the mode); until then the caller must not read or reuse them, and results are bit-identical to serial searches.
+ * Calls with a host-side query or output buffer are unaffected (they join first and complete before returning). */
+int crh_index_set_overlap(crh_index *h, int enable, void *stream);
+/* Makes `stream` wait (on the device; the host does not block) for the overlapped searches in flight: all of them, or all
+ * but the `keep_last` batches enqueued last (a batch = one scan pass: up to 64 queries, or up to 256 of a longer call) -- the
+ * form a pipelined caller uses: search(i+1); search(i+2); join(keep_last = 2); consume results i on `stream` (e.g. the all-gather + crh_merge_topk of a row-sharded search).  Candidate-buffer overflow
+ * is still only detected and repaired by crh_search_finish. */
+int crh_search_join(crh_index *h, void *stream, int keep_last);
+
 int crh_search_get_stats(crh_index *h, crh_search_stats *out);
 
 /* HIP-event timing of the dominant kernel (the corpus scan), recorded on the search stream around
