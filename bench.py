@@ -653,12 +653,11 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
     def once():
         if multi:
             idx.search(qd, K, row_base=row_base, out_scores=loc_s, out_rows=loc_r, stream=stream)
-            idx.search_finish(stream)
             dist.all_gather_into_tensor(gathered.view(-1), local)
             ffi.merge_topk(gat_s, gat_r, s, r, stream)
         else:
             idx.search(qd, K, row_base=row_base, out_scores=s, out_rows=r, stream=stream)
-            idx.search_finish(stream)
+        # (stream order carries the results on; crh_search_finish after the loop checks that no candidate buffer overflowed)
         cols = side.gather(r, row_base=row_base, stream=stream)
         if multi:
             dist.all_reduce(cols.packed, op=dist.ReduceOp.SUM)
@@ -667,6 +666,7 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
 
     for _ in range(3):
         out = once()
+    idx.search_finish(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -674,10 +674,13 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
     t0 = time.perf_counter()
     for _ in range(steps):
         out = once()
+    idx.search_finish(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = (time.perf_counter() - t0) / steps
+    if idx.stats()["fallback_used"]:
+        raise RuntimeError("a candidate buffer overflowed inside the timed config-5 steps")
     scan_ms, launches = idx.profile()
     idx.set_profiling(False)
     t0 = time.perf_counter()
