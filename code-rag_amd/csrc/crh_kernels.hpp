@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_scan_ring(
         }
         f32x16 a0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a0[r] = NC == 4 ? (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[NC - 1][r]) : acc[0][r] + acc[NC - 1][r];
+        for (int r = 0; r < 16; ++r) a0[r] = NC == 4 ? (acc[0][r] + acc[1][r]) + (acc[NC > 2 ? 2 : 0][r] + acc[NC - 1][r]) : acc[0][r] + acc[NC - 1][r];
         const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
 
         if (MODE == 0) {
