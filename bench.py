@@ -85,10 +85,6 @@ def parse_args():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--seed-tiles", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=0, help="steps in flight with overlap (0: the library's default, ffi.OVERLAP_LANES)")
-    ap.add_argument("--overlap", action="store_true", help="run the HEADLINE steps overlapped (crh_index_set_overlap, --lanes steps in "
-                    "flight); default: every step completes on the launch stream before the next one starts, and the overlapped "
-                    "form is measured beside it as the `overlapped` sub-record")
     ap.add_argument("--embed-chunks", type=int, default=100000, help="synthetic chunks for the encoder leg (BASELINE configs[1]: 100k synthetic code chunks)")
     ap.add_argument("--e2e-texts", type=int, default=20000, help="texts of the embed_e2e leg")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -233,31 +229,17 @@ def build_corpus(torch, ffi, dev, rows, dtype, seed, check_rows, code_cols=1, st
     return idx, head, head_codes
 
 
-NSLOTS = 10  # rotating output buffers: more than the steps in flight
+NSLOTS = 4  # rotating output buffers
 
 
-LANES = [5]  # steps in flight when overlapped (run() sets it from --lanes / ffi.OVERLAP_LANES)
-
-
-def run_steps(idx, n, launch, complete, stream, overlap):
-    """n steps.  Serial: launch(i); complete(i).  Overlapped (crh_index_set_overlap): the pipelined form -- steps i+1 .. i+depth go
-    out before step i is joined to the launch stream and consumed: depth + 1 = ffi.OVERLAP_LANES steps in flight."""
-    if not overlap:
-        for i in range(n):
-            launch(i)
-            complete(i)
-        return
-    depth = LANES[0] - 1
-    for j in range(min(depth, n)):
-        launch(j)
+def run_steps(n, launch, complete):
+    """n steps: every step completes on the launch stream before the next one starts."""
     for i in range(n):
-        if i + depth < n:
-            launch(i + depth)
-        idx.search_join(stream, keep_last=min(depth, n - 1 - i))
+        launch(i)
         complete(i)
 
 
-def timed_search(torch, idx, qd, K, filters, steps, warmup, stream, overlap=False):
+def timed_search(torch, idx, qd, K, filters, steps, warmup, stream):
     """warmup + `steps` timed batches of one configuration: wall around a full synchronize, per-step device stamps on the
     launch stream (the completion of step i, joined to it), HIP-event time of the scan kernel from the library's own profiling."""
     import numpy as np
@@ -269,20 +251,18 @@ def timed_search(torch, idx, qd, K, filters, steps, warmup, stream, overlap=Fals
     def launch(i):
         idx.search(qd, K, filters=filters, out_scores=out_s[i % NSLOTS], out_rows=out_r[i % NSLOTS], stream=stream)
 
-    idx.set_overlap(LANES[0] if overlap else 0, stream)
-    run_steps(idx, warmup, launch, lambda i: None, stream, overlap)
+    run_steps(warmup, launch, lambda i: None)
     idx.search_finish(stream)
     torch.cuda.synchronize()
     idx.set_profiling(True)
     t0 = time.perf_counter()
     ev[0].record()
-    run_steps(idx, steps, launch, lambda i: ev[i + 1].record(), stream, overlap)
+    run_steps(steps, launch, lambda i: ev[i + 1].record())
     idx.search_finish(stream)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     scan_ms, launches = idx.profile()
     idx.set_profiling(False)
-    idx.set_overlap(False, stream)
     per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
     last = (steps - 1) % NSLOTS
     return {"ms_per_step": wall * 1e3 / steps, "step_ms_device": pct(per), "scan_ms": scan_ms / max(1, launches),
@@ -378,15 +358,12 @@ def run(args, json_fd) -> None:
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     ev_x = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if dist is not None else None
 
-    overlap = args.overlap
-    LANES[0] = args.lanes if args.lanes > 1 else ffi.OVERLAP_LANES
     timing = [False]
 
     def launch(i: int) -> None:
         idx.search(qd, K, row_base=row_base, out_scores=out_s[i % nslots], out_rows=out_r[i % nslots], stream=stream)
 
     def complete(i: int) -> None:
-        # (overlapped: run_steps has joined step i to the launch stream; step i+1 is already in flight in the other lane)
         if dist is not None:
             if timing[0]:
                 ev_x[i].record()
@@ -401,36 +378,24 @@ def run(args, json_fd) -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    idx.set_overlap(LANES[0] if overlap else 0, stream)
-    run_steps(idx, args.warmup, launch, complete, stream, overlap)
+    run_steps(args.warmup, launch, complete)
     idx.search_finish(stream)
     fence()
     idx.set_profiling(True)
     timing[0] = True
     t0 = time.perf_counter()
     ev[0].record()
-    run_steps(idx, args.steps, launch, complete, stream, overlap)
+    run_steps(args.steps, launch, complete)
     idx.search_finish(stream)  # also verifies no candidate buffer overflowed in any timed step
     fence()
     dt = time.perf_counter() - t0
     timing[0] = False
-    idx.set_overlap(False, stream)
     log(f"search timed: {args.steps} steps in {dt:.3f} s")
     per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
     exchange = np.array([ev_x[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]) if dist is not None else None
     scan_ms_total, scan_launches = idx.profile()
     idx.set_profiling(False)
     stats = idx.stats()
-    # the same steps in the other mode, for comparison (one GPU only; never the headline)
-    serial = overlapped = None
-    if dist is None:
-        ro = timed_search(torch, idx, qd, K, None, args.steps, 2, stream, overlap=not overlap)
-        rec = {"ms_per_step": ro["ms_per_step"], "kernel_ms": ro["scan_ms"], "step_ms_device": ro["step_ms_device"]}
-        if overlap:
-            serial = rec
-        else:
-            overlapped = dict(rec, lanes=LANES[0], identical_to_headline=bool(torch.equal(ro["rows"], out_r[(args.steps - 1) % nslots])
-                                                                              and torch.equal(ro["scores"], out_s[(args.steps - 1) % nslots])))
     last = (args.steps - 1) % nslots
     headline_rows = out_r[last].clone()          # this rank's local top-k of the last timed step (global row ids)
 
@@ -494,11 +459,6 @@ def run(args, json_fd) -> None:
                    "precision": ("bf16 corpus and queries on MFMA, f32 accumulate, canonical f32 re-score of the survivors" if args.dtype == "bf16"
                                  else "f32 store: bf16 MFMA scan nominates, f32 canonical re-score decides")},
         "roofline": roof,
-        "overlap": ({"lanes": LANES[0], "what": "crh_index_set_overlap: that many steps in flight; main scans back to back on one stream, "
-                     "the query preparation / seed scan / threshold / selection kernels of several steps side by side between them"}
-                    if overlap else None),
-        "serial": serial,
-        "overlapped": overlapped,
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
         "rccl_ranks": rccl_ranks if args.backend == "nccl" else None,
@@ -527,7 +487,7 @@ def run(args, json_fd) -> None:
                 out[name] = {"error": repr(e)}
 
     def filtered_leg():
-        r = timed_search(torch, idx, qd, K, [(0, 1)], args.sub_steps, 3, stream, overlap)
+        r = timed_search(torch, idx, qd, K, [(0, 1)], args.sub_steps, 3, stream)
         res = {"workload": f"{N}x{D} {args.dtype}, batch-{B} top-{K}, filter language == code 1 of 3 (uniform)",
                "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7), "unit": out["unit"], "ms_per_step": r["ms_per_step"],
                "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
@@ -544,7 +504,7 @@ def run(args, json_fd) -> None:
         q512 = np.random.default_rng(11).standard_normal((nq, D)).astype(np.float32)
         q512[:B] = qs
         qd512 = torch.from_numpy(q512).to(dev)
-        r = timed_search(torch, idx, qd512, K, None, max(5, args.sub_steps // 2), 2, stream, overlap)
+        r = timed_search(torch, idx, qd512, K, None, max(5, args.sub_steps // 2), 2, stream)
         flops = 2.0 * 256 * N * D
         ach = flops / (r["scan_ms"] * 1e-3) / 1e12 if r["scan_ms"] > 0 else 0.0
         same = bool(torch.equal(r["rows"][:B], headline_rows - row_base))
@@ -579,7 +539,7 @@ def run(args, json_fd) -> None:
     def f32_leg():
         f32, h32, hc32 = build_corpus(torch, ffi, dev, N, ffi.DTYPE_F32, 20251226 + rank, args.check_rows, 1, stream, args.seed_tiles)
         try:
-            r = timed_search(torch, f32, qd, K, None, args.sub_steps, 3, stream, overlap)
+            r = timed_search(torch, f32, qd, K, None, args.sub_steps, 3, stream)
             a_, b_ = r["rows"].cpu().numpy(), (headline_rows - row_base).cpu().numpy()
             full = float(np.mean([len(np.intersect1d(x, y)) / K for x, y in zip(a_, b_)])) if args.dtype == "bf16" else None
             res = {"workload": f"{N}x{D} f32 store (bf16 MFMA scan nominates, f32 master re-scores), batch-{B} top-{K}",

@@ -80,6 +80,35 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// ------------------------------------------------------------------ packed rows: offsets are device data, so they are clamped
+// Row b of a packed batch = tokens [row_off[b], row_off[b+1]) of a T-token axis, at most Lmax of them.  The library cannot
+// look at a device array when a call is made, so every kernel clamps what it reads: a bad offsets array gives wrong rows,
+// never an access outside the buffers; k_check_row_off reports it (crh_encoder_finish).
+__device__ __forceinline__ void packed_row(const int32_t *__restrict__ row_off, int b, int T, int Lmax, int64_t &r0, int &L)
+{
+    int a = row_off[b], e = row_off[b + 1];
+    a = a < 0 ? 0 : (a > T ? T : a);
+    e = e < a ? a : (e > T ? T : e);
+    r0 = a;
+    L = (e - a) < Lmax ? (e - a) : Lmax;
+}
+// status bits: 1 row_off[0] != 0, 2 decreasing, 4 a row longer than Lmax, 8 row_off[B] != T
+__global__ __launch_bounds__(256) void k_check_row_off(const int32_t *__restrict__ row_off, int B, int T, int Lmax, unsigned int *status)
+{
+    unsigned int bad = 0u;
+    for (int i = threadIdx.x; i <= B; i += 256) {
+        const int v = row_off[i];
+        if (i == 0 && v != 0) bad |= 1u;
+        if (i == B && v != T) bad |= 8u;
+        if (i < B) {
+            const int n = row_off[i + 1] - v;
+            if (n < 0) bad |= 2u;
+            if (n > Lmax) bad |= 4u;
+        }
+    }
+    if (bad) __hip_atomic_fetch_or(status, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------ embeddings + LayerNorm
 
 // grid = (B, L/16), block = 256: a workgroup embeds 16 tokens of one row (one row per workgroup left a single query on one
@@ -90,14 +119,16 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
                                                   const bf16_t *__restrict__ pos, const bf16_t *__restrict__ type0,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                   int pad_id, bf16_t *__restrict__ out, unsigned long long *__restrict__ kmask,
-                                                  int Lpad, int D, const int32_t *__restrict__ row_off)
+                                                  int Lpad, int D, const int32_t *__restrict__ row_off, int T)
 {
     extern __shared__ int posid[];  // [L]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // packed rows (row_off != NULL): row b holds the tokens [row_off[b], row_off[b+1]) of a flat id array, no padding between
     // rows; Lpad (a multiple of 16, >= every row) only sizes the mask stride and the grid.  Padded rows: L = Lpad tokens at b*Lpad.
-    const int64_t r0 = row_off ? (int64_t)row_off[b] : (int64_t)b * Lpad;
-    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
+    // Whatever row_off holds, the row is clamped to the T tokens of the buffers and to Lpad tokens (see packed_row).
+    int64_t r0 = (int64_t)b * Lpad;
+    int L = Lpad;
+    if (row_off) packed_row(row_off, b, T, Lpad, r0, L);
     if ((int)blockIdx.y * 16 >= L && blockIdx.y != 0) return;      // (block y = 0 of a row always writes the row's mask words)
     const int32_t *row = ids + r0;
     const int nw = (Lpad + 63) >> 6;                 // mask words per row (Lpad is a multiple of 16, not necessarily of 64)
@@ -537,7 +568,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 template <int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv, const unsigned long long *__restrict__ kmask,
                                                   bf16_t *__restrict__ out, int Lpad, int H, float scale_log2,
-                                                  const int32_t *__restrict__ row_off)
+                                                  const int32_t *__restrict__ row_off, int T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kv[];
     unsigned char *Ks = kv, *Vs = kv + (size_t)((Lpad + 63) & ~63) * 128;
@@ -547,12 +578,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
     const int ld = 3 * H * 64;
     // packed rows (row_off != NULL): row b = tokens [row_off[b], row_off[b+1]) of the flat token axis; its 16-row query tiles and
     // 64-key tiles may reach into the next row's tokens -- those keys are masked, those query rows are computed and NOT stored
-    const size_t r0 = row_off ? (size_t)row_off[b] : (size_t)b * Lpad;
-    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
-    const bf16_t *base = qkv + r0 * ld + h * 64;
+    int64_t r0s = (int64_t)b * Lpad;
+    int L = Lpad;
+    if (row_off) packed_row(row_off, b, T, Lpad, r0s, L);   // (clamped to the T tokens of the buffers, whatever row_off holds)
+    const size_t r0 = (size_t)r0s;
     const int nkt = (Lpad + 63) >> 6;                // mask words per row; a 64-key tile may reach past L (those keys are masked)
     const unsigned long long *km = kmask + (size_t)b * nkt;
-    const size_t last_row = (row_off ? (size_t)row_off[gridDim.y] : (size_t)gridDim.y * Lpad) - 1;   // never read past the buffer
+    const size_t last_row = (row_off ? (size_t)T : (size_t)gridDim.y * Lpad) - 1;   // never read past the buffer
 
     // last 64-key tile that holds a valid key: nothing beyond it is staged or visited
     int last = -1;
@@ -718,15 +750,17 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
 // bit after the load: padded rows are real memory); the four partial sums are added in wave order.  (One thread per dim
 // walking every token behind a branch on its mask bit was a chain of L dependent loads: 31 us at B = 16, L = 128.)
 __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, const unsigned long long *__restrict__ kmask,
-                                              float *__restrict__ sent, int Lpad, int D, const int32_t *__restrict__ row_off)
+                                              float *__restrict__ sent, int Lpad, int D, const int32_t *__restrict__ row_off, int T)
 {
     __shared__ float part[4][64][2];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = blockIdx.x * 128 + lane * 2;
     const int nw = (Lpad + 63) >> 6;
     const unsigned long long *km = kmask + (size_t)b * nw;
-    const size_t r0 = row_off ? (size_t)row_off[b] : (size_t)b * Lpad;
-    const int L = row_off ? row_off[b + 1] - row_off[b] : Lpad;
+    int64_t r0s = (int64_t)b * Lpad;
+    int L = Lpad;
+    if (row_off) packed_row(row_off, b, T, Lpad, r0s, L);
+    const size_t r0 = (size_t)r0s;
     const bf16_t *base = tok + r0 * D + d;
     float a0 = 0.f, a1 = 0.f;
     for (int t = wave; t < L; t += 32) {
@@ -1176,6 +1210,23 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
 }
 #endif  // CRH_ENABLE_DEBUG
 
+// One GEMM of any tiled kernel with epilogue `epi` (0 bias, 2 bias + residual)
+static int launch_tiled(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
+{
+    const GemmKernel which = choose_gemm(T, N, K, 0);
+    if (which == GEMM_MID) return epi == 2 ? launch_mid<2>(x, w, bias, res, y, T, N, K, st) : launch_mid<0>(x, w, bias, nullptr, y, T, N, K, st);
+    if (which == GEMM_PP) return launch_gemm256(epi, x, w, bias, res, y, T, N, K, st);
+    CRH_TRY(gemm_lds_attr());
+    if (epi == 2)
+        hipLaunchKernelGGL((k_gemm_nt<2, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+                           (const bf16_t *)res, (bf16_t *)y, T, N, K);
+    else
+        hipLaunchKernelGGL((k_gemm_nt<0, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+                           (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual, const float *gamma,
                               const float *beta, float eps, void *y, int T, int N, int K, void *stream)
 {
@@ -1183,57 +1234,83 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     if (N != 768) return fail(CRH_E_INVALID, "gemm_res_ln: N=%d (the fused LayerNorm is built for 768)", N);
     if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_ln: shape T=%d K=%d", T, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // WHERE the residual joins depends on the shape of the operation only, never on T or on which kernel the cost model picks --
+    // so that a token's result has the same rounding points in a batch of 40 tokens and in one of 65 536 (the tiled kernels
+    // add the same products in the same order; tests/test_encoder_gpu.py pins a chunk's embedding across batches to the bit):
+    //   K <= 1024 (the O-projection): bias-only epilogue, the GEMM output rounded to bf16, residual added in f32 by the LayerNorm
+    //     kernel (k_layernorm768_res).  The residual epilogue would pull 128 KB of cold residual per CU and tile with the
+    //     matrix pipe idle: +31 us per call at 65 k tokens against +18 us for the LayerNorm's extra read.
+    //   K  > 1024 (FFN2): residual added to the f32 accumulator in the GEMM epilogue, one rounding, plain LayerNorm after.
+    // (y == residual with K <= 1024 cannot take the first form -- the GEMM would overwrite the residual -- and falls to the second.)
+    const bool ln_side = K <= 1024 && y != residual;
+    const int epi = ln_side ? 0 : 2;
     if (use_skinny(T, N, K) && y != residual) {
-        hipLaunchKernelGGL((k_gemm_skinny<2>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)residual, (bf16_t *)y, T, N, K);
+        if (epi == 2)
+            hipLaunchKernelGGL((k_gemm_skinny<2>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)residual, (bf16_t *)y, T, N, K);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<0>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
         CRH_HIP(hipGetLastError());
+    } else {
+        CRH_TRY(launch_tiled(epi, x, w, bias, residual, y, T, N, K, st));
+    }
+    if (ln_side)
+        hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
+    else
         hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    }
-    const GemmKernel which = choose_gemm(T, N, K, 0);
-    if (which == GEMM_MID) {     // (in place is fine: a lane reads exactly the residual elements it then overwrites)
-        CRH_TRY(launch_mid<2>(x, w, bias, residual, y, T, N, K, st));
-        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    }
-    if (which == GEMM_PP && K <= 1024 && y != residual) {
-        // short K: the residual joins in the LayerNorm kernel instead of the GEMM epilogue (see k_layernorm768_res)
-        CRH_TRY(launch_gemm256(0, x, w, bias, nullptr, y, T, N, K, st));
-        hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma,
-                           beta, eps, T);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    }
-    if (which == GEMM_PP) {
-        CRH_TRY(launch_gemm256(2, x, w, bias, residual, y, T, N, K, st));
-        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    }
-    CRH_TRY(gemm_lds_attr());
-    hipLaunchKernelGGL((k_gemm_nt<2, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
-                       (const bf16_t *)residual, (bf16_t *)y, T, N, K);
-    CRH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
 
-static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int L, int H, void *stream);
+static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int T, int L, int H, void *stream);
+
+// ---- verdict of the device-side row_off checks: one word per device in pinned host memory (the kernel ORs into it at system
+// scope; the host peeks at it without synchronising).  Bits: see k_check_row_off.
+static unsigned int *packed_status_word()
+{
+    static unsigned int *words[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return nullptr;
+    d &= 63;
+    if (!words[d]) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *static_cast<volatile unsigned int *>(p) = 0u;
+        words[d] = static_cast<unsigned int *>(p);
+    }
+    return words[d];
+}
+// CRH_E_INVALID once a check has found a bad offsets array (the word is cleared: one report per offence)
+static int packed_verdict()
+{
+    unsigned int *w = packed_status_word();
+    if (!w) return fail(CRH_E_HIP, "packed rows: no status word (hipHostMalloc failed)");
+    const unsigned int bad = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+    if (!bad) return CRH_OK;
+    return fail(CRH_E_INVALID, "packed rows: the device-side check rejected row_off:%s%s%s%s (what it described was clamped to the buffers; the results of that forward are meaningless)",
+                (bad & 1u) ? " row_off[0] != 0;" : "", (bad & 2u) ? " offsets decrease;" : "", (bad & 4u) ? " a row is longer than Lmax;" : "",
+                (bad & 8u) ? " row_off[B] != T;" : "");
+}
+
+int crh_encoder_finish(void *stream)
+{
+    CRH_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return packed_verdict();
+}
 
 int crh_attn_fwd_varlen(const void *qkv, const uint64_t *kmask, void *out, int B, int L, int H, void *stream)
 {
-    return attn_launch(qkv, kmask, out, nullptr, B, L, H, stream);
+    return attn_launch(qkv, kmask, out, nullptr, B, B * L, L, H, stream);
 }
 
-int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int Lmax, int H, void *stream)
+int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int T, int Lmax, int H, void *stream)
 {
     if (!row_off) return fail(CRH_E_INVALID, "attn_packed: row_off is NULL");
-    return attn_launch(qkv, kmask, out, row_off, B, Lmax, H, stream);
+    if (T <= 0) return fail(CRH_E_INVALID, "attn_packed: T=%d tokens", T);
+    CRH_TRY(packed_verdict());
+    return attn_launch(qkv, kmask, out, row_off, B, T, Lmax, H, stream);
 }
 
-static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int L, int H, void *stream)
+static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int T, int L, int H, void *stream)
 {
     if (!qkv || !kmask || !out) return fail(CRH_E_INVALID, "attn: NULL pointer");
     if (B <= 0 || H <= 0 || L <= 0 || L % 16 || L > 512) return fail(CRH_E_INVALID, "attn: B=%d L=%d H=%d (need L%%16==0, L<=512)", B, L, H);
@@ -1253,7 +1330,7 @@ static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const 
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<NW_, QT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256)); \
         }                                                                                                                       \
         hipLaunchKernelGGL((k_attn<NW_, QT_>), dim3(H, B), dim3(NW_ * 64), lds, st, (const bf16_t *)qkv,                        \
-                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2, row_off);                        \
+                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2, row_off, T);                     \
     } while (0)
     static int force = -1;   // CODERAG_HIP_ATTN_CFG=<waves> (4, 8, 16; tuning only)
     if (force < 0) {
@@ -1279,17 +1356,22 @@ int crh_embed_ln(const int32_t *ids, const void *word, const void *pos, const vo
     if (B <= 0 || L <= 0 || L % 16 || L > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln: B=%d L=%d D=%d (need L%%16==0, D==768)", B, L, D);
     hipLaunchKernelGGL(k_embed_ln, dim3(B, L / 16), dim3(256), (size_t)L * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
                        (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, L, D,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, B * L);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
 int crh_embed_ln_packed(const int32_t *ids, const int32_t *row_off, const void *word, const void *pos, const void *type0, const float *gamma,
-                        const float *beta, float eps, int pad_id, void *out, uint64_t *kmask, int B, int Lmax, int D, void *stream)
+                        const float *beta, float eps, int pad_id, void *out, uint64_t *kmask, int B, int T, int Lmax, int D, void *stream)
 {
     if (!ids || !row_off || !word || !pos || !type0 || !gamma || !beta || !out || !kmask) return fail(CRH_E_INVALID, "embed_ln_packed: NULL pointer");
-    if (B <= 0 || Lmax <= 0 || Lmax % 16 || Lmax > 1024 || D != 768) return fail(CRH_E_INVALID, "embed_ln_packed: B=%d Lmax=%d D=%d (need Lmax%%16==0, D==768)", B, Lmax, D);
+    if (B <= 0 || T <= 0 || Lmax <= 0 || Lmax % 16 || Lmax > 1024 || D != 768)
+        return fail(CRH_E_INVALID, "embed_ln_packed: B=%d T=%d Lmax=%d D=%d (need T>0, Lmax%%16==0, D==768)", B, T, Lmax, D);
+    CRH_TRY(packed_verdict());
+    // the first call of a forward: the whole offsets array is checked on the device (the kernels below only clamp)
+    hipLaunchKernelGGL(k_check_row_off, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), row_off, B, T, Lmax, packed_status_word());
+    CRH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_embed_ln, dim3(B, Lmax / 16), dim3(256), (size_t)Lmax * 4, static_cast<hipStream_t>(stream), ids, (const bf16_t *)word,
-                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, Lmax, D, row_off);
+                       (const bf16_t *)pos, (const bf16_t *)type0, gamma, beta, eps, pad_id, (bf16_t *)out, (unsigned long long *)kmask, Lmax, D, row_off, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -1299,16 +1381,17 @@ int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, in
     if (!tok || !kmask || !sent) return fail(CRH_E_INVALID, "pool: NULL pointer");
     if (B <= 0 || L <= 0 || L % 16 || D % 128) return fail(CRH_E_INVALID, "pool: B=%d L=%d D=%d", B, L, D);
     hipLaunchKernelGGL(k_pool, dim3(D / 128, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
-                       (const unsigned long long *)kmask, sent, L, D, (const int32_t *)nullptr);
+                       (const unsigned long long *)kmask, sent, L, D, (const int32_t *)nullptr, B * L);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
-int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int Lmax, int D, void *stream)
+int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int T, int Lmax, int D, void *stream)
 {
     if (!tok || !row_off || !kmask || !sent) return fail(CRH_E_INVALID, "pool_packed: NULL pointer");
-    if (B <= 0 || Lmax <= 0 || Lmax % 16 || D % 128) return fail(CRH_E_INVALID, "pool_packed: B=%d Lmax=%d D=%d", B, Lmax, D);
+    if (B <= 0 || T <= 0 || Lmax <= 0 || Lmax % 16 || D % 128) return fail(CRH_E_INVALID, "pool_packed: B=%d T=%d Lmax=%d D=%d", B, T, Lmax, D);
+    CRH_TRY(packed_verdict());
     hipLaunchKernelGGL(k_pool, dim3(D / 128, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)tok,
-                       (const unsigned long long *)kmask, sent, Lmax, D, row_off);
+                       (const unsigned long long *)kmask, sent, Lmax, D, row_off, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -47,8 +47,6 @@ struct Pending {
 struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
-    bool use_ring = false;  // <= 64 queries: k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs) instead of k_scan
-    int spare_cus = 0;     // CUs the main scans leave to the small kernels of the other lane (overlapped searches)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
@@ -60,15 +58,8 @@ struct crh_index {
     // tuning
     int seed_tiles = 4096, wave_cap = 2048, qcap = 65536, force_fallback = 0;
 
-    // search workspace: LANES (lazily sized; lane 0 is the one serial searches use).  Everything a batch writes between its query
-    // preparation and its final selection lives in one lane, so several batches may be in flight at once.  With overlap on,
-    // consecutive batches take the lanes in turn: a lane's own stream carries the batch's head (query preparation, seed scan,
-    // threshold) and its selection, ONE stream shared by all lanes carries the main scans, back to back in batch order.  The
-    // small kernels cannot run while a main scan fills the GPU; they run in the gap that opens when the next scan's head is not
-    // ready yet -- once every nlanes-1 scans, the heads and selections of nlanes-1 batches side by side (a selection alone fills
-    // 64 CUs for ~60 us, a seed scan is bandwidth-bound at ~40 us): per batch ~ seed + (selection + preparation + threshold) /
-    // (nlanes-1) instead of their sum.
-    struct Lane {
+    // search workspace (lazily sized): everything a batch writes between its query preparation and its final selection
+    struct Workspace {
         int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
         int64_t ws_mask_tiles = 0;
         float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
@@ -76,18 +67,8 @@ struct crh_index {
         uint32_t *effmask = nullptr;
         u32x2 *qlist = nullptr;
         unsigned long long *skeys = nullptr;
-        hipStream_t st = nullptr;                 // overlap only: the lane's own stream, forked from / joined to the caller's
-        hipEvent_t fork = nullptr, done = nullptr, head_done = nullptr, scan_done = nullptr;
-        bool in_flight = false;                   // work enqueued on `st` that the caller's stream has not been joined to
-        int64_t seq = 0;                          // number of the last batch enqueued here (crh_index::batch_seq)
     };
-    static constexpr int kLanes = 8;   // at most; `nlanes` of them are in use
-    Lane lane[kLanes];
-    int nlanes = 4;
-    bool overlap = false;
-    hipStream_t scan_st = nullptr;   // overlap only: every main scan, in batch order
-    int next_lane = 0;
-    int64_t batch_seq = 0;
+    Workspace ws;
     SearchStatus *status = nullptr;
     float *stage_q = nullptr;
     int64_t stage_q_elems = 0;
@@ -150,13 +131,13 @@ int ensure_stage_in(crh_index *h, int64_t bytes)
 int scan_blocks(const crh_index *h, int64_t nitems)
 {
     int64_t b = ceil_div(nitems, kWaves);
-    if (b > h->cu_count - h->spare_cus) b = h->cu_count - h->spare_cus;
+    if (b > h->cu_count) b = h->cu_count;
     if (b < 1) b = 1;
     return (int)b;
 }
 
-// (re)allocate one lane of the search workspace for the given candidate capacities
-int ensure_workspace(crh_index *h, crh_index::Lane &w, int wave_cap, int qcap)
+// (re)allocate the search workspace for the given candidate capacities
+int ensure_workspace(crh_index *h, crh_index::Workspace &w, int wave_cap, int qcap)
 {
     const int blocks = h->cu_count;
     if (!w.qn) CRH_TRY(dev_alloc(&w.qn, (int64_t)kWideQ * h->dim));
@@ -199,25 +180,11 @@ int ensure_workspace(crh_index *h, crh_index::Lane &w, int wave_cap, int qcap)
     }
     return CRH_OK;
 }
-// lane 0 at the current tuning: what the entry points outside crh_search work in
+// the workspace at the current tuning: what the entry points outside crh_search work in
 int ensure_workspace0(crh_index *h)
 {
-    crh_index::Lane &w = h->lane[0];
+    crh_index::Workspace &w = h->ws;
     return ensure_workspace(h, w, std::max(h->wave_cap, w.ws_wave_cap), std::max(h->qcap, w.ws_qcap));
-}
-
-// Make `st` wait for everything the lanes still have in flight (no host synchronisation).  Every entry point that reads or
-// writes what a search reads -- and the end of every search that is not left overlapped -- passes through here.
-int join_lanes(crh_index *h, hipStream_t st, int keep_last = 0)
-{
-    for (int l = 0; l < crh_index::kLanes; ++l) {
-        crh_index::Lane &w = h->lane[l];
-        if (w.in_flight && w.seq <= h->batch_seq - keep_last) {
-            CRH_HIP(hipStreamWaitEvent(st, w.done, 0));
-            w.in_flight = false;
-        }
-    }
-    return CRH_OK;
 }
 
 __global__ void k_fill_pad(float *s, int64_t *r, int64_t n)
@@ -229,7 +196,7 @@ __global__ void k_fill_pad(float *s, int64_t *r, int64_t n)
     }
 }
 
-int build_mask(crh_index *h, crh_index::Lane &w, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
+int build_mask(crh_index *h, crh_index::Workspace &w, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
 {
     if (nfilt == 0) {
         *mask_out = h->alive;
@@ -253,7 +220,7 @@ int build_mask(crh_index *h, crh_index::Lane &w, const crh_filter *filters, int 
 
 // scan kernel instantiations: k-steps = dim / 16; 64 queries per pass except for dim 1536 (32: LDS)
 template <int MODE>
-int launch_scan(crh_index *h, crh_index::Lane &w, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
+int launch_scan(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
                 SearchStatus *stt)
 {
 #define CRH_SCAN(KS, QB)                                                                                                       \
@@ -271,32 +238,9 @@ int launch_scan(crh_index *h, crh_index::Lane &w, int blocks, hipStream_t st, co
     return CRH_OK;
 }
 
-// the ring scan (<= 64 queries): two computing waves per workgroup, each sees EVERY tile of its workgroup for its 32 queries
-// (k_scan: 16 waves share them), so the workgroup's share of the candidate workspace is cut into 2 lists of 8 x wave_cap
-constexpr int kRingWaves = 2;
-template <int MODE>
-int launch_scan_ring(crh_index *h, crh_index::Lane &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
-                     SearchStatus *stt)
-{
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
-#define CRH_RING(KS)                                                                                                               \
-    hipLaunchKernelGGL((k_scan_ring<KS, MODE>), dim3(blocks), dim3(256), 0, st, h->xt, w.qfrag, w.tau, mask, nitems, stride, nblk, \
-                       w.gmax, w.wave_lists, kRingWaves, wave_cap * (kWaves / kRingWaves), stt->qcount, w.qlist, qcap, stt)
-    switch (h->ksteps) {
-    case 24: CRH_RING(24); break;
-    case 48: CRH_RING(48); break;
-    case 64: CRH_RING(64); break;
-    case 96: CRH_RING(96); break;
-    default: return fail(CRH_E_INTERNAL, "no ring scan kernel for %d k-steps", h->ksteps);
-    }
-#undef CRH_RING
-    CRH_HIP(hipGetLastError());
-    return CRH_OK;
-}
-
 // the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
 template <int MODE>
-int launch_scan_wide(crh_index *h, crh_index::Lane &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
+int launch_scan_wide(crh_index *h, crh_index::Workspace &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
                      SearchStatus *stt)
 {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(nitems, h->cu_count));
@@ -314,12 +258,9 @@ int launch_scan_wide(crh_index *h, crh_index::Lane &w, hipStream_t st, const uin
 }
 
 // one batch (<= batch_q queries through k_scan, or up to kWideQ through k_scan_wide), everything enqueued on `st`
-int enqueue_batch(crh_index *h, crh_index::Lane &w, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
-                  int64_t *out_r, int slot, hipStream_t st, hipStream_t scan_st = nullptr)
+int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
+                  int64_t *out_r, int slot, hipStream_t st)
 {
-    // scan_st (overlapped searches): the stream every main scan of the index runs on, one after the other -- `st` then carries only
-    // this batch's head (query preparation, seed scan, threshold) and its selection, tied to the scan by the lane's two events
-    const bool split = scan_st != nullptr && scan_st != st;
     const int64_t ntiles = ceil_div(h->count, kTileRows);
     if (ntiles == 0) {
         CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
@@ -345,32 +286,18 @@ int enqueue_batch(crh_index *h, crh_index::Lane &w, const float *q_dev, int nq, 
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
-    const bool ring = !wide && h->use_ring;
     if (wide)
         CRH_TRY(launch_scan_wide<0>(h, w, st, mask, G, stride, nblk, wave_cap, qcap, stt));
-    else if (ring)
-        CRH_TRY(launch_scan_ring<0>(h, w, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else
         CRH_TRY(launch_scan<0>(h, w, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
     hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, w.gmax, G, k, margin, nq, w.tau, qstride);
     CRH_HIP(hipGetLastError());
-    hipStream_t ss = split ? scan_st : st;
-    if (split) {
-        CRH_HIP(hipEventRecord(w.head_done, st));
-        CRH_HIP(hipStreamWaitEvent(ss, w.head_done, 0));
-    }
-    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], ss));
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
     if (wide)
-        CRH_TRY(launch_scan_wide<1>(h, w, ss, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
-    else if (ring)
-        CRH_TRY(launch_scan_ring<1>(h, w, ss, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
+        CRH_TRY(launch_scan_wide<1>(h, w, st, mask, (int)ntiles, 1, nblk, wave_cap, qcap, stt));
     else
-        CRH_TRY(launch_scan<1>(h, w, scan_blocks(h, ntiles), ss, mask, (int)ntiles, 1, wave_cap, qcap, stt));
-    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], ss));
-    if (split) {
-        CRH_HIP(hipEventRecord(w.scan_done, ss));
-        CRH_HIP(hipStreamWaitEvent(st, w.scan_done, 0));
-    }
+        CRH_TRY(launch_scan<1>(h, w, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
+    if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
         hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
@@ -394,7 +321,6 @@ int next_pow2(int64_t v)
 
 int finish_pending(crh_index *h, hipStream_t st)
 {
-    CRH_TRY(join_lanes(h, st));
     if (h->pending.empty()) return CRH_OK;
     CRH_HIP(hipStreamSynchronize(st));
     const int used = std::max(1, std::min(h->next_slot, kStatusSlots));   // slots are handed out in order from 0
@@ -403,7 +329,7 @@ int finish_pending(crh_index *h, hipStream_t st)
     std::vector<Pending> todo;
     todo.swap(h->pending);
     h->next_slot = 0;
-    crh_index::Lane &w = h->lane[0];   // (everything is idle: a batch that overflowed is re-run alone, in lane 0, on `st`)
+    crh_index::Workspace &w = h->ws;   // (everything is idle: a batch that overflowed is re-run alone on `st`)
     for (const Pending &p : todo) {
         SearchStatus s = host[p.slot];
         if (h->profiling && h->count > 0) {
@@ -486,20 +412,12 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     crh_index *h = new crh_index();
     h->dim = dim;
     h->ksteps = dim / 16;
-    {   // CODERAG_HIP_SCAN=ring selects k_scan_ring (corpus through the LDS-DMA ring) for the <= 64-query passes instead of
-        // k_scan (corpus straight into registers).  Measured at 10M x 768, 64 queries: k_scan 2.30 ms, k_scan_ring 2.34 ms
-        // (profiles/r02_wide_scan.md) -- the ring's data path is faster (7.0 vs 6.97 TB/s loads-only), but its two computing
-        // waves cannot hide the per-tile epilogue the way k_scan's sixteen do; it stays an option, not the default
-        const char *e = getenv("CODERAG_HIP_SCAN");
-        h->use_ring = e && strcmp(e, "ring") == 0;
-    }
-    h->batch_q = (dim > 1024 && !h->use_ring) ? 32 : 64;   // (k_scan's 64-query image does not fit LDS at dim 1536)
+    h->batch_q = dim > 1024 ? 32 : 64;   // (k_scan's 64-query image does not fit LDS at dim 1536)
     h->wide_ok = dim <= 768 && getenv("CODERAG_HIP_NO_WIDE_SCAN") == nullptr;   // (the env switch exists for A/B timing only)
     h->dtype = dtype;
     h->ncols = n_code_cols;
     h->device = device;
     h->cu_count = prop.multiProcessorCount;
-    if (const char *e = getenv("CODERAG_HIP_SPARE_CUS")) h->spare_cus = std::max(0, std::min(atoi(e), h->cu_count - 8));
     h->cap_rows = (capacity_rows + 31) & ~31LL;
     h->cap_tiles = h->cap_rows / 32;
     int rc = dev_alloc(&h->xt, h->cap_tiles * h->ksteps * 64);
@@ -529,7 +447,8 @@ int crh_index_destroy(crh_index *h)
     dev_free(h->alive);
     dev_free(h->codes);
     dev_free(h->scratch_u32);
-    for (auto &w : h->lane) {
+    {
+        crh_index::Workspace &w = h->ws;
         dev_free(w.qn);
         dev_free(w.gmax);
         dev_free(w.tau);
@@ -538,13 +457,7 @@ int crh_index_destroy(crh_index *h)
         dev_free(w.effmask);
         dev_free(w.qlist);
         dev_free(w.skeys);
-        if (w.fork) (void)hipEventDestroy(w.fork);
-        if (w.done) (void)hipEventDestroy(w.done);
-        if (w.head_done) (void)hipEventDestroy(w.head_done);
-        if (w.scan_done) (void)hipEventDestroy(w.scan_done);
-        if (w.st) (void)hipStreamDestroy(w.st);
     }
-    if (h->scan_st) (void)hipStreamDestroy(h->scan_st);
     dev_free(h->status);
     dev_free(h->stage_q);
     dev_free(h->stage_os);
@@ -584,7 +497,6 @@ static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device
                     (long long)h->cap_rows);
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    CRH_TRY(join_lanes(h, st));   // overlapped searches still in flight read the last tile and its alive word
     const int64_t chunk = 65536;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
@@ -629,7 +541,6 @@ int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows)
     if (n <= 0) return CRH_OK;
     if (!rows) return fail(CRH_E_INVALID, "rows is NULL");
     DeviceGuard g(h->device);
-    CRH_TRY(join_lanes(h, nullptr));
     CRH_TRY(ensure_stage_in(h, n * 8));
     CRH_HIP(hipMemcpy(h->stage_in, rows, (size_t)n * 8, hipMemcpyHostToDevice));
     CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
@@ -653,7 +564,7 @@ int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_fi
     CRH_HIP(hipDeviceSynchronize());   // searches in flight on other streams read `alive` / the shared mask buffer
     CRH_TRY(ensure_workspace0(h));
     const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, h->lane[0], filters, n_filters, &mask, nullptr));
+    CRH_TRY(build_mask(h, h->ws, filters, n_filters, &mask, nullptr));
     const int64_t ntiles = ceil_div(h->count, 32);
     CRH_HIP(hipMemset(h->scratch_u32, 0, 4));
     hipLaunchKernelGGL(k_tombstone_mask, dim3((unsigned)ceil_div(ntiles, 256)), dim3(256), 0, 0, h->alive, mask, ntiles, h->scratch_u32);
@@ -662,6 +573,100 @@ int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_fi
     CRH_HIP(hipMemcpy(&cleared, h->scratch_u32, 4, hipMemcpyDeviceToHost));
     h->alive_count -= cleared;
     if (n_cleared_out) *n_cleared_out = cleared;
+    return CRH_OK;
+}
+
+int crh_index_compact(crh_index *h, int64_t *old_to_new_host, int64_t *rows_after)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (rows_after) *rows_after = h->alive_count;
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());   // searches in flight on any stream read what is about to move
+    if (!h->pending.empty()) return fail(CRH_E_INVALID, "compact: searches with device outputs are pending (call crh_search_finish first)");
+    const int64_t count = h->count, ntiles = ceil_div(count, 32);
+    if (count == 0) return CRH_OK;
+    if (h->alive_count == count) {   // nothing to reclaim: the identity map
+        if (old_to_new_host)
+            for (int64_t r = 0; r < count; ++r) old_to_new_host[r] = r;
+        return CRH_OK;
+    }
+    // per-tile prefix of the alive counts (host: ntiles words, 1.25 MB per 10M rows)
+    std::vector<uint32_t> words((size_t)ntiles);
+    CRH_HIP(hipMemcpy(words.data(), h->alive, (size_t)ntiles * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> prefix((size_t)ntiles);
+    int64_t new_count = 0;
+    for (int64_t t = 0; t < ntiles; ++t) {
+        prefix[(size_t)t] = new_count;
+        new_count += __builtin_popcount(words[(size_t)t]);
+    }
+    if (new_count != h->alive_count) return fail(CRH_E_INTERNAL, "compact: %lld alive bits, %lld alive rows on record", (long long)new_count, (long long)h->alive_count);
+    const int64_t new_tiles = ceil_div(new_count, 32);
+    // The rows only ever move DOWN (new <= old), so the image is compacted in place, chunk by chunk through a bounce buffer:
+    // the new tiles [c, c + C) are gathered from old rows >= 32 c -- which no earlier chunk has overwritten -- and then copied
+    // over the old tiles [c, c + C), which no later chunk reads.  The chunk bounds the extra memory (1M rows: 1.5 GB of tiles).
+    const int64_t chunk_tiles = std::min<int64_t>(std::max<int64_t>(new_tiles, 1), 1 << 15);
+    const int64_t chunk_rows = chunk_tiles * 32;
+    const size_t per_row = std::max<size_t>((size_t)h->dim * 2, h->xf32 ? (size_t)h->dim * 4 : 0);
+    int64_t *d_prefix = nullptr, *d_o2n = nullptr;
+    int32_t *d_n2o = nullptr;
+    void *bounce = nullptr;
+    auto cleanup = [&]() {
+        if (d_prefix) (void)hipFree(d_prefix);
+        if (d_o2n) (void)hipFree(d_o2n);
+        if (d_n2o) (void)hipFree(d_n2o);
+        if (bounce) (void)hipFree(bounce);
+    };
+#define CRH_CPT(expr)                                                                                                        \
+    do {                                                                                                                     \
+        hipError_t e_ = (expr);                                                                                              \
+        if (e_ != hipSuccess) {                                                                                              \
+            cleanup();                                                                                                       \
+            return fail(CRH_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);               \
+        }                                                                                                                    \
+    } while (0)
+    CRH_CPT(hipMalloc(reinterpret_cast<void **>(&d_prefix), (size_t)ntiles * 8));
+    CRH_CPT(hipMalloc(reinterpret_cast<void **>(&d_o2n), (size_t)count * 8));
+    CRH_CPT(hipMalloc(reinterpret_cast<void **>(&d_n2o), (size_t)std::max<int64_t>(new_count, 1) * 4));
+    CRH_CPT(hipMalloc(&bounce, (size_t)chunk_rows * per_row));
+    CRH_CPT(hipMemcpy(d_prefix, prefix.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_compact_map, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, 0, h->alive, d_prefix, count, d_o2n, d_n2o);
+    CRH_CPT(hipGetLastError());
+    const size_t tile_bytes = (size_t)h->ksteps * 1024;
+    const int row16 = h->dim / 4;   // 16-byte pieces of an f32 row
+    for (int64_t t0 = 0; t0 < new_tiles; t0 += chunk_tiles) {
+        const int64_t nt = std::min(chunk_tiles, new_tiles - t0), r0 = t0 * 32, nr = nt * 32;
+        hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, 0, h->xt, h->ksteps, d_n2o, new_count, t0, static_cast<u32x4 *>(bounce));
+        CRH_CPT(hipGetLastError());
+        CRH_CPT(hipMemcpyAsync(reinterpret_cast<char *>(h->xt) + (size_t)t0 * tile_bytes, bounce, (size_t)nt * tile_bytes, hipMemcpyDeviceToDevice, 0));
+        if (h->xf32) {
+            hipLaunchKernelGGL(k_compact_rows16, dim3((unsigned)ceil_div(nr * row16, 256)), dim3(256), 0, 0, reinterpret_cast<const u32x4 *>(h->xf32), row16,
+                               d_n2o, new_count, r0, nr, static_cast<u32x4 *>(bounce));
+            CRH_CPT(hipGetLastError());
+            CRH_CPT(hipMemcpyAsync(h->xf32 + r0 * h->dim, bounce, (size_t)nr * h->dim * 4, hipMemcpyDeviceToDevice, 0));
+        }
+        for (int c = 0; c < h->ncols; ++c) {
+            int32_t *col = h->codes + (int64_t)c * h->cap_rows;
+            hipLaunchKernelGGL(k_compact_i32, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, 0, col, d_n2o, new_count, r0, nr, (int32_t)-1,
+                               static_cast<int32_t *>(bounce));
+            CRH_CPT(hipGetLastError());
+            CRH_CPT(hipMemcpyAsync(col + r0, bounce, (size_t)nr * 4, hipMemcpyDeviceToDevice, 0));
+        }
+    }
+    // what lies beyond the new end goes back to the state crh_index_create leaves: zero tiles, no alive bits, codes -1
+    if (ntiles > new_tiles) {
+        CRH_CPT(hipMemsetAsync(reinterpret_cast<char *>(h->xt) + (size_t)new_tiles * tile_bytes, 0, (size_t)(ntiles - new_tiles) * tile_bytes, 0));
+        for (int c = 0; c < h->ncols; ++c)
+            CRH_CPT(hipMemsetAsync(h->codes + (int64_t)c * h->cap_rows + new_tiles * 32, 0xff, (size_t)(ntiles - new_tiles) * 32 * 4, 0));
+    }
+    hipLaunchKernelGGL(k_compact_alive, dim3((unsigned)ceil_div(ntiles, 256)), dim3(256), 0, 0, h->alive, new_count, ntiles);
+    CRH_CPT(hipGetLastError());
+    if (old_to_new_host) CRH_CPT(hipMemcpy(old_to_new_host, d_o2n, (size_t)count * 8, hipMemcpyDeviceToHost));
+    CRH_CPT(hipDeviceSynchronize());
+#undef CRH_CPT
+    cleanup();
+    h->count = new_count;
+    h->alive_count = new_count;
+    if (rows_after) *rows_after = new_count;
     return CRH_OK;
 }
 
@@ -830,9 +835,8 @@ int crh_debug_read_ceiling(crh_index *h, void *stream)
     DeviceGuard g(h->device);
     const int64_t ntiles = ceil_div(h->count, kTileRows);
     if (ntiles == 0) return CRH_OK;
-    CRH_TRY(join_lanes(h, static_cast<hipStream_t>(stream)));
     CRH_TRY(ensure_workspace0(h));
-    crh_index::Lane &w = h->lane[0];
+    crh_index::Workspace &w = h->ws;
     const uint32_t *mask = nullptr;
     CRH_TRY(build_mask(h, w, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
     return launch_scan<2>(h, w, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, w.ws_wave_cap, w.ws_qcap, h->status);
@@ -863,12 +867,9 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     // force_fallback (testing): start from absurdly small candidate buffers so the regrow-and-rerun path runs
-    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->lane[0].ws_wave_cap);
-    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->lane[0].ws_qcap);
-    // overlapped: device-resident queries and outputs only (a host buffer is read / filled synchronously, below)
-    const bool overlapped = h->overlap && queries_on_device && out_on_device;
-    if (!overlapped) CRH_TRY(join_lanes(h, st));
-    CRH_TRY(ensure_workspace(h, h->lane[0], wc, qc));
+    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
+    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->ws.ws_qcap);
+    CRH_TRY(ensure_workspace(h, h->ws, wc, qc));
 
     const float *q_dev = queries;
     if (!queries_on_device) {
@@ -904,25 +905,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         const int left = nq - q0;
         b = (h->wide_ok && left > h->batch_q) ? std::min(kWideQ, left) : std::min(h->batch_q, left);
         if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
-        // the lane of this batch and the stream it runs on: serial = lane 0 on the caller's stream; overlapped = the lanes in
-        // turn, each on its own stream, entered through an event recorded on the caller's stream at this call (what the caller
-        // enqueued before the call -- the queries -- is complete before the lane reads it) and left through the lane's `done`
-        // event, which the caller's stream waits for in crh_search_finish or the next entry point that is not an overlapped search
-        crh_index::Lane &w = h->lane[overlapped ? h->next_lane : 0];
-        hipStream_t run = st;
-        if (overlapped) {
-            h->next_lane = (h->next_lane + 1) % h->nlanes;
-            if (!w.st) {
-                CRH_HIP(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
-                CRH_HIP(hipEventCreateWithFlags(&w.fork, hipEventDisableTiming));
-                CRH_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
-                CRH_HIP(hipEventCreateWithFlags(&w.head_done, hipEventDisableTiming));
-                CRH_HIP(hipEventCreateWithFlags(&w.scan_done, hipEventDisableTiming));
-                if (!h->scan_st) CRH_HIP(hipStreamCreateWithFlags(&h->scan_st, hipStreamNonBlocking));
-            }
-            CRH_TRY(ensure_workspace(h, w, wc, qc));
-            run = w.st;
-        }
+        crh_index::Workspace &w = h->ws;
         Pending p{};
         p.nq = b;
         p.k = k;
@@ -934,18 +917,9 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         p.out_r = orow + (int64_t)q0 * k;
         p.slot = h->next_slot++;
         const uint32_t *mask = nullptr;
-        if (overlapped) {
-            CRH_HIP(hipEventRecord(w.fork, st));
-            CRH_HIP(hipStreamWaitEvent(run, w.fork, 0));
-        }
-        // (a filter mask lives in the lane: the lane's stream orders its rebuild after the lane's previous scan)
-        CRH_TRY(build_mask(h, w, filters, n_filters, &mask, run));
-        CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, run, overlapped ? h->scan_st : nullptr));
-        if (overlapped) {
-            CRH_HIP(hipEventRecord(w.done, run));
-            w.in_flight = true;
-            w.seq = ++h->batch_seq;
-        }
+        // (the filter mask lives in the workspace: stream order puts its rebuild behind the previous batch's scan)
+        CRH_TRY(build_mask(h, w, filters, n_filters, &mask, st));
+        CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
         h->pending.push_back(p);
     }
     if (!out_on_device || !queries_on_device) {
@@ -955,24 +929,6 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
             CRH_HIP(hipMemcpy(out_rows, h->stage_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
         }
     }
-    return CRH_OK;
-}
-
-int crh_search_join(crh_index *h, void *stream, int keep_last)
-{
-    if (!h) return fail(CRH_E_INVALID, "index is NULL");
-    DeviceGuard g(h->device);
-    return join_lanes(h, static_cast<hipStream_t>(stream), keep_last < 0 ? 0 : keep_last);
-}
-
-int crh_index_set_overlap(crh_index *h, int enable, void *stream)
-{
-    if (!h) return fail(CRH_E_INVALID, "index is NULL");
-    DeviceGuard g(h->device);
-    CRH_TRY(join_lanes(h, static_cast<hipStream_t>(stream)));
-    h->overlap = enable != 0;
-    h->nlanes = enable <= 1 ? 4 : std::min(enable, (int)crh_index::kLanes);   // 1 = the default depth
-    h->next_lane = 0;
     return CRH_OK;
 }
 
@@ -1047,10 +1003,9 @@ int crh_index_match_rows(crh_index *h, const crh_filter *filters, int n_filters,
     if (limit <= 0 || h->count == 0) return CRH_OK;   // (rows_out_host == NULL: count only, up to `limit`)
     if (n_filters < 0 || n_filters > CRH_MAX_FILTERS) return fail(CRH_E_INVALID, "n_filters=%d outside 0..%d", n_filters, CRH_MAX_FILTERS);
     DeviceGuard g(h->device);
-    CRH_TRY(join_lanes(h, nullptr));
     CRH_TRY(ensure_workspace0(h));
     const uint32_t *mask = nullptr;
-    CRH_TRY(build_mask(h, h->lane[0], filters, n_filters, &mask, nullptr));
+    CRH_TRY(build_mask(h, h->ws, filters, n_filters, &mask, nullptr));
     const int64_t ntiles = ceil_div(h->count, 32);
     std::vector<uint32_t> hm((size_t)ntiles);
     CRH_HIP(hipMemcpy(hm.data(), mask, (size_t)ntiles * 4, hipMemcpyDeviceToHost));

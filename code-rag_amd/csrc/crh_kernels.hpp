@@ -241,6 +241,75 @@ __global__ void k_untile_rows(const u32x4 *__restrict__ xt, int ksteps, int64_t 
     o[7] = bf16_bits_f32(pk.w >> 16);
 }
 
+// ------------------------------------------------------------------ compaction (crh_index_compact)
+
+// Stable compaction of the rows: tile_prefix[t] = alive rows in the tiles before t (host prefix sum of the popcounts).
+// One thread per OLD row: its new number is tile_prefix + the alive bits below it in its own tile.
+__global__ __launch_bounds__(256) void k_compact_map(const uint32_t *__restrict__ alive, const int64_t *__restrict__ tile_prefix, int64_t count,
+                                                     int64_t *__restrict__ old_to_new, int32_t *__restrict__ new_to_old)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const uint32_t w = alive[r >> 5];
+    const int b = (int)(r & 31);
+    int64_t n = -1;
+    if ((w >> b) & 1u) {
+        n = tile_prefix[r >> 5] + __popc(w & ((1u << b) - 1u));
+        new_to_old[n] = (int32_t)r;
+    }
+    old_to_new[r] = n;
+}
+
+// New tiles [t0, t0 + nt) of the tiled bf16 image into a bounce buffer: one workgroup per new tile, 64 lanes x ksteps pieces;
+// lane (h, r) of piece s copies the 16 bytes of old row new_to_old[32 t + r] (zeros past the new row count).
+__global__ __launch_bounds__(256) void k_compact_tiles(const u32x4 *__restrict__ xt, int ksteps, const int32_t *__restrict__ new_to_old,
+                                                       int64_t new_count, int64_t t0, u32x4 *__restrict__ bounce)
+{
+    const int64_t t = t0 + blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    const int64_t nr = t * 32 + r;
+    const int64_t old = nr < new_count ? (int64_t)new_to_old[nr] : -1;
+    for (int s = wave; s < ksteps; s += 4) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (old >= 0) v = xt[tiled_index(old >> 5, ksteps, s, h, (int)(old & 31))];
+        bounce[((size_t)blockIdx.x * ksteps + s) * 64 + lane] = v;
+    }
+}
+
+// rows [r0, r0 + n) of a row-major array of `row16` 16-byte pieces per row (the f32 master) into a bounce buffer
+__global__ __launch_bounds__(256) void k_compact_rows16(const u32x4 *__restrict__ src, int row16, const int32_t *__restrict__ new_to_old,
+                                                        int64_t new_count, int64_t r0, int64_t n, u32x4 *__restrict__ bounce)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * row16) return;
+    const int64_t lr = i / row16;
+    const int c = (int)(i - lr * row16);
+    const int64_t nr = r0 + lr;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (nr < new_count) v = src[(size_t)new_to_old[nr] * row16 + c];
+    bounce[i] = v;
+}
+
+// one int32 column, rows [r0, r0 + n): `fill` past the new row count
+__global__ __launch_bounds__(256) void k_compact_i32(const int32_t *__restrict__ col, const int32_t *__restrict__ new_to_old, int64_t new_count,
+                                                     int64_t r0, int64_t n, int32_t fill, int32_t *__restrict__ bounce)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t nr = r0 + i;
+    bounce[i] = nr < new_count ? col[new_to_old[nr]] : fill;
+}
+
+// alive words after compaction: rows [0, new_count) alive, nothing beyond
+__global__ void k_compact_alive(uint32_t *__restrict__ alive, int64_t new_count, int64_t ntiles)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const int64_t left = new_count - t * 32;
+    alive[t] = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+}
+
 // ------------------------------------------------------------------ query preparation
 
 // One block (64 threads) per query slot 0..63.  Slots >= nq become all-zero queries.
@@ -495,210 +564,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     }
 }
 
-// ------------------------------------------------------------------ the ring scan (<= 64 queries, corpus through LDS)
-
-// k_scan streams every corpus tile straight into MFMA operand registers; its loads alone reach 6.97 TB/s and the scan 96-97 %
-// of that.  An LDS-DMA ring moves data faster still: 7.0 TB/s with all its waits and barriers (profiles/r02_wide_scan.md).
-// k_scan_ring: a workgroup is 4 waves, ONE per SIMD.  Waves 0 and 1 each keep ONE 32-query block as MFMA B fragments in
-// registers for the whole kernel (KSTEPS x 4: 192 at dim 768) and run the block's dot products on NC alternating accumulators
-// -- a single dependent chain of v_mfma_f32_32x32x16_bf16 advances only every ~120 cycles, so a wave alone on its SIMD needs
-// several independent chains; they are added once per tile.  Waves 2 and 3 compute nothing: they keep the ring fed (their
-// DMA issues come right after each barrier; the computing waves issue theirs between MFMAs).
-// Ring: chunks of CH k-steps (12 KB at dim 768), RING chunks = 144 KB, RING-2 in flight; one raw s_barrier per chunk: each
-// wave first waits (counted vmcnt) for its own pieces of chunk g+1, so after the barrier chunk g+1 has landed for everybody
-// (the fragment reads run ahead into it) and everybody is done with chunk g-1, whose slot chunk g+RING-1 is then issued into.
-// NCH divides RING, so a tile's chunks are contiguous in the ring.  Past the workgroup's last tile the ring is refilled with
-// chunks nobody reads, so that the counted wait is ONE constant.  ONE __shared__ object (a second one beside an LDS-DMA
-// target makes hipcc drain vmcnt before every LDS read).  Thresholds, candidate compaction and the hand-over are k_scan's.
-// A K-split variant (4 computing waves = 2 blocks x 2 K-halves, partial sums swapped through LDS) was built first: 3.0 ms
-// with contiguous halves, 2.53 with even / odd k-steps -- the fold, the exchange and four short MFMA bursts per tile cost more
-// than they saved; two computing waves beside two pure movers is both simpler and faster.
-template <int N>
-__device__ __forceinline__ void vm_wait()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(256) void k_scan_ring(
-    const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
-    const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, int nblk, float *__restrict__ gmax,
-    u32x4 *__restrict__ wave_lists, int lists_per_block, int wave_cap, unsigned int *__restrict__ qcount,
-    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
-{
-    constexpr int WAVES = 4;
-    constexpr int CH = (KSTEPS % 16 == 0) ? 16 : 12;       // k-steps (1-KiB pieces) per ring chunk
-    constexpr int NCH = KSTEPS / CH;                       // chunks per tile
-    constexpr int RING = (144 / CH / NCH) * NCH;           // <= 144 KB of ring, whole tiles
-    constexpr int PPC = CH / WAVES;                        // pieces of a chunk issued by each wave
-    constexpr int PF = 6;                                  // corpus fragments read ahead of their MFMAs
-    constexpr int NC = 2;                                  // independent accumulation chains per computing wave (4: 2.47 ms, the fold costs more than the chains gain)
-    static_assert(KSTEPS % CH == 0 && CH % WAVES == 0 && RING >= 4 && KSTEPS > PF && (RING - 3) * PPC < 64, "ring geometry");
-    __shared__ u32x4 ring[RING * CH * 64];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
-    const bool active = wave < nblk;                       // nblk <= 2: waves 2 and 3 never compute
-
-    u32x4 qreg[KSTEPS];
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) qreg[s] = active ? qfrag[((size_t)wave * KSTEPS + s) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
-    float t0 = 0.f;
-    if (MODE == 1) t0 = active ? tau[wave * 32 + (lane & 31)] : INFINITY;
-
-    const int nmine = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    u32x4 *mylist = wave_lists + ((size_t)blockIdx.x * lists_per_block + wave) * wave_cap;
-    unsigned int wcnt = 0;
-
-    auto src_of = [&](int g) {          // chunk g of this workgroup, clamped to its last tile; wave-uniform (scalar registers)
-        const int jj = (g / NCH) < nmine ? (g / NCH) : nmine - 1;
-        const int64_t tile = (int64_t)((int)blockIdx.x + jj * (int)gridDim.x) * tile_stride;
-        return xt + ((size_t)tile * KSTEPS + (g % NCH) * CH + wave * PPC) * 64;
-    };
-    auto dst_of = [&](int g) { return ring + ((size_t)(g % RING) * CH + wave * PPC) * 64; };
-    auto issue_piece = [&](const u32x4 *src, u32x4 *dst, int p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
-                                         (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
-    };
-    if (nmine > 0) {
-        for (int g = 0; g < RING - 1; ++g) {
-            const u32x4 *src = src_of(g);
-            u32x4 *dst = dst_of(g);
-#pragma unroll
-            for (int p = 0; p < PPC; ++p) issue_piece(src, dst, p);
-        }
-    }
-
-    if (!active) {   // a wave without queries only moves data: the same waits, barriers and refills, nothing else
-        for (int g = 0; g < nmine * NCH; ++g) {
-            vm_wait<(RING - 3) * PPC>();
-            __builtin_amdgcn_s_barrier();
-            const u32x4 *rsrc = src_of(g + RING - 1);
-            u32x4 *rdst = dst_of(g + RING - 1);
-#pragma unroll
-            for (int p = 0; p < PPC; ++p) issue_piece(rsrc, rdst, p);
-        }
-    }
-    for (int j = 0; active && j < nmine; ++j) {
-        const int item = (int)blockIdx.x + j * (int)gridDim.x;
-        const int64_t tile = (int64_t)item * tile_stride;
-        const u32x4 *lp = ring + (size_t)((j * NCH) % RING) * CH * 64 + lane;
-        f32x16 acc[NC];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = f32x16{0};
-        u32x4 af[PF + 1];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int g = j * NCH + c;
-            vm_wait<(RING - 3) * PPC>();                   // my pieces of chunk g+1 have landed
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const u32x4 *rsrc = src_of(g + RING - 1);      // refill: into the slot chunk g-1 was read from
-            u32x4 *rdst = dst_of(g + RING - 1);
-            if (c == 0) {
-#pragma unroll
-                for (int s = 0; s < PF; ++s) af[s] = lp[s * 64];
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int s = c * CH + t;
-                if (s + PF < KSTEPS) af[(s + PF) % (PF + 1)] = lp[(s + PF) * 64];
-                acc[s % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s % (PF + 1)]),
-                                                                      __builtin_bit_cast(bf16x8, qreg[s]), acc[s % NC], 0, 0, 0);
-                if (t % WAVES == 1) issue_piece(rsrc, rdst, t / WAVES);     // DMA issues go between the MFMAs
-                __builtin_amdgcn_sched_barrier(0);   // keep the read PF steps ahead of its use (the scheduler sinks it otherwise)
-            }
-        }
-        f32x16 a0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a0[r] = NC == 4 ? (acc[0][r] + acc[1][r]) + (acc[NC > 2 ? 2 : 0][r] + acc[NC - 1][r]) : acc[0][r] + acc[NC - 1][r];
-        const uint32_t vmask = rowmask[tile];              // wave-uniform -> scalar load
-
-        if (MODE == 0) {
-            float m0 = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                m0 = fmaxf(m0, ((vmask >> row) & 1u) ? a0[r] : -INFINITY);
-            }
-            m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            if (h == 0) gmax[(size_t)item * 64 + wave * 32 + lane] = m0;
-        } else {
-            float m0 = a0[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, a0[r]);
-            if (__ballot(m0 >= t0) != 0ull && vmask != 0u) {
-                uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
-                asm volatile("" : "+v"(rowbase));   // keep the 16 row numbers out of the loop-invariant registers (rare path)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    const int rbit = row + 4 * h;
-                    const float sc = a0[r];
-                    const bool pass = ((vmask >> rbit) & 1u) && (sc >= t0);
-                    const unsigned long long pm = __ballot(pass);
-                    if (pm != 0ull) {
-                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-                        const unsigned int pos = wcnt + pre;
-                        if (pass && pos < (unsigned int)wave_cap) {
-                            u32x4 e;
-                            e.x = f32_bits(sc);
-                            e.y = rowbase + row;
-                            e.z = (uint32_t)(wave * 32 + (lane & 31));
-                            e.w = 0u;
-                            mylist[pos] = e;
-                        }
-                        wcnt += (unsigned int)__popcll(pm);
-                    }
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    if (MODE == 1) {
-        // hand the workgroup's candidates over to the per-query lists (as k_scan does)
-        __syncthreads();   // every wave is done with the ring, and its list stores have completed
-        unsigned int *wc = reinterpret_cast<unsigned int *>(ring);   // [WAVES] counts, [64] hist, [64] base, [64] off
-        unsigned int *hist = wc + WAVES;
-        unsigned int *base = hist + 64;
-        unsigned int *off = base + 64;
-        if (lane == 0) {
-            wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
-            atomicMax(&status->max_wave_cnt, wcnt);
-            if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
-        }
-        if (tid < 64) {
-            hist[tid] = 0u;
-            off[tid] = 0u;
-        }
-        __syncthreads();
-        const u32x4 *wl = wave_lists + (size_t)blockIdx.x * lists_per_block * wave_cap;
-        for (int w = 0; w < 2; ++w) {
-            const unsigned int n = wc[w];
-            for (unsigned int e = tid; e < n; e += WAVES * 64) atomicAdd(&hist[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) base[tid] = hist[tid] ? atomicAdd(&qcount[tid], hist[tid]) : 0u;
-        __syncthreads();
-        for (int w = 0; w < 2; ++w) {
-            const unsigned int n = wc[w];
-            for (unsigned int e = tid; e < n; e += WAVES * 64) {
-                const u32x4 c = wl[(size_t)w * wave_cap + e];
-                const unsigned int q = c.z & 63u;
-                const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
-                if (idx < (unsigned int)qcap) {
-                    u32x2 o;
-                    o.x = c.x;
-                    o.y = c.y;
-                    qlist[(size_t)q * qcap + idx] = o;
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ the wide scan (65 .. 256 queries per corpus pass)
 
 // k_scan keeps the QUERIES in LDS and streams the corpus through registers: 64 queries per pass is what 96 KB of LDS holds,
@@ -716,6 +581,12 @@ __global__ __launch_bounds__(256) void k_scan_ring(
 // tile j has landed for everybody AND everybody is done reading tile j-1, whose slot the DMA of tile j+SLOTS-1 is then
 // issued into.  Thresholds, candidate compaction and the hand-over to the per-query lists are k_scan's (one 32-query
 // block per wave instead of two).  nblk = number of 32-query blocks in use: waves beyond it only move data.
+template <int N>
+__device__ __forceinline__ void vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(512) void k_scan_wide(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,

@@ -208,11 +208,13 @@ class HipUniXcoder:
         check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
         return sent
 
-    def forward_packed(self, ids, row_off, Lmax: int):
+    def forward_packed(self, ids, row_off, Lmax: int, verify: bool = False):
         """The forward on a batch WITHOUT padding: ``ids`` int32 CUDA tensor [T] (the rows' tokens back to back), ``row_off``
         int32 CUDA tensor [B + 1] (row b = ids[row_off[b]:row_off[b+1]]), ``Lmax`` a multiple of 16 >= every row's length.
         Returns f32 [B, 768].  GEMMs and LayerNorms run on the T real tokens; attention, the embedding gather and the pool
-        take the row offsets (``crh_*_packed``).  Same arithmetic per token as :meth:`forward_ids`."""
+        take the row offsets (``crh_*_packed``).  Same arithmetic per token as :meth:`forward_ids`.  The kernels clamp every row to
+        the T tokens of the buffers and a device-side check of ``row_off`` reports a bad array as ``NativeError(E_INVALID)`` at the
+        next packed call -- or right here with ``verify=True`` (which waits for the stream)."""
         torch, L_ = self._torch, ffi.lib()
         ffi.use_device(self.device.index)
         B, T = int(row_off.shape[0]) - 1, int(ids.shape[0])
@@ -229,14 +231,16 @@ class HipUniXcoder:
         px, px1, pqkv, pctx, phid, pkm, psent, poff = (int(t.data_ptr()) for t in (x, x1, qkv, ctx, hid, kmask, sent, row_off))
         eps, check = cfg.layer_norm_eps, ffi.check
         gemm, gemm_ln = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln
-        check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, Lmax, H, st))
+        check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, T, Lmax, H, st))
         for ly in self._layer_ptrs:
             check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
-            check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, Lmax, cfg.num_heads, st))
+            check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, T, Lmax, cfg.num_heads, st))
             check(gemm_ln(pctx, ly["o_w"], ly["o_b"], px, ly["ln1_g"], ly["ln1_b"], eps, px1, T, H, H, st))
             check(gemm(px1, ly["f1_w"], ly["f1_b"], phid, T, F, H, 1, st))
             check(gemm_ln(phid, ly["f2_w"], ly["f2_b"], px1, ly["ln2_g"], ly["ln2_b"], eps, px, T, H, F, st))
-        check(L_.crh_masked_mean_pool_packed(px, poff, pkm, psent, B, Lmax, H, st))
+        check(L_.crh_masked_mean_pool_packed(px, poff, pkm, psent, B, T, Lmax, H, st))
+        if verify:      # the sync point of a forward: the verdict of the device-side check of row_off (crh_encoder_finish)
+            check(L_.crh_encoder_finish(st))
         return sent
 
     def pack_rows(self, id_rows, rows):

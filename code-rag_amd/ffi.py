@@ -18,19 +18,19 @@ LIB_PATH = Path(os.environ.get("CODERAG_HIP_LIB", PKG_DIR / "lib" / "libcoderag_
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NODEVICE, E_INTERNAL = 0, -1, -2, -3, -4, -5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_FILTERS, MAX_K = 8, 1024
-OVERLAP_LANES = 4      # crh_index_set_overlap(enable = 1): batches in flight; a pipelined caller keeps OVERLAP_LANES - 1 ahead
+ABI_VERSION = 2        # CRH_ABI_VERSION of include/coderag_hip.h
 
 # every symbol include/coderag_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "crh_abi_version", "crh_last_error", "crh_device_count", "crh_device_info",
     "crh_index_create", "crh_index_destroy", "crh_index_append", "crh_index_append_preprocessed", "crh_index_tombstone",
-    "crh_index_tombstone_filter", "crh_index_export", "crh_index_import",
+    "crh_index_tombstone_filter", "crh_index_compact", "crh_index_export", "crh_index_import",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
-    "crh_search", "crh_search_finish", "crh_index_set_overlap", "crh_search_join", "crh_search_get_stats", "crh_index_set_tuning",
+    "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
-    "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed",
+    "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed", "crh_encoder_finish",
 )
 # exported by lib/libcoderag_hip_debug.so only (same sources built with -DCRH_ENABLE_DEBUG; tools/ and kernel tests)
 DEBUG_EXPORTS = ("crh_debug_gemm_variant", "crh_debug_read_ceiling")
@@ -125,6 +125,7 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_index_append_preprocessed.argtypes = [vp, i64, f32p, i32, vp, C.POINTER(i64), vp]
     L.crh_index_tombstone.argtypes = [vp, i64, vp]
     L.crh_index_tombstone_filter.argtypes = [vp, C.POINTER(Filter), i32, C.POINTER(i64)]
+    L.crh_index_compact.argtypes = [vp, vp, C.POINTER(i64)]
     L.crh_index_export.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.crh_index_import.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
     L.crh_index_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
@@ -133,8 +134,6 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_index_read_rows.argtypes = [vp, i64, i64, vp]
     L.crh_search.argtypes = [vp, i32, vp, i32, i32, C.POINTER(Filter), i32, i64, vp, vp, i32, vp]
     L.crh_search_finish.argtypes = [vp, vp]
-    L.crh_index_set_overlap.argtypes = [vp, i32, vp]
-    L.crh_search_join.argtypes = [vp, vp, i32]
     L.crh_search_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
     L.crh_index_set_tuning.argtypes = [vp, i32, i32, i32, i32]
     L.crh_index_set_profiling.argtypes = [vp, i32]
@@ -147,9 +146,10 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    L.crh_embed_ln_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
-    L.crh_attn_fwd_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
-    L.crh_masked_mean_pool_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.crh_embed_ln_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, i32, vp]
+    L.crh_attn_fwd_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.crh_masked_mean_pool_packed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.crh_encoder_finish.argtypes = [vp]
     L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -160,7 +160,7 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     for name in EXPORTS + (DEBUG_EXPORTS if debug else ()):
         if name != "crh_last_error":
             getattr(L, name).restype = i32
-    if L.crh_abi_version() != 1:
+    if L.crh_abi_version() != ABI_VERSION:
         raise NativeError(E_INTERNAL, f"ABI version mismatch between ffi.py and {path.name}")
     return L
 
@@ -307,6 +307,15 @@ class Index:
         check(lib().crh_index_tombstone_filter(self._handle(), farr, nf, C.byref(n)))
         return int(n.value)
 
+    def compact(self) -> np.ndarray:
+        """Reclaim the rows of deleted points (``crh_index_compact``): the alive rows move down in their old order.  Returns
+        ``old_to_new`` (int64 per old row: its new row number, -1 for a deleted one)."""
+        rows, _ = self.count()
+        o2n = np.empty((rows,), dtype=np.int64)
+        after = C.c_int64(0)
+        check(lib().crh_index_compact(self._handle(), o2n.ctypes.data if rows else None, C.byref(after)))
+        return o2n
+
     # ------------------------------------------------------------------ snapshot (SURVEY.md section 8f, row 2)
     SNAPSHOT_FORMAT = 2
     SNAPSHOT_CHUNK_TILES = 1 << 15          # 32768 tiles = 1M rows per transfer (1.5 GiB of tiles at dim 768)
@@ -444,17 +453,6 @@ class Index:
 
     def search_finish(self, stream: int = 0) -> None:
         check(lib().crh_search_finish(self._handle(), stream))
-
-    def set_overlap(self, enable: bool | int, stream: int = 0) -> None:
-        """Overlapped device-to-device searches: consecutive :meth:`search` calls run in internal lanes
-        (``True``: OVERLAP_LANES of them; an int > 1: that many) so the small kernels of several batches run side by side
-        between main scans instead of one after the other.  Outputs are complete only after
-        :meth:`search_finish` (include/coderag_hip.h, crh_index_set_overlap)."""
-        check(lib().crh_index_set_overlap(self._handle(), int(enable), stream))
-
-    def search_join(self, stream: int = 0, keep_last: int = 0) -> None:
-        """Device-side join of the overlapped searches in flight (all, or all but the last ``keep_last`` batches) into ``stream``."""
-        check(lib().crh_search_join(self._handle(), stream, int(keep_last)))
 
     def stats(self) -> dict:
         s = SearchStats()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRH_ABI_VERSION 1
+#define CRH_ABI_VERSION 2
 
 /* status codes */
 #define CRH_OK 0
@@ -99,7 +99,7 @@ int crh_index_append(crh_index *h, int64_t n, const float *vecs, int on_device,
 int crh_index_append_preprocessed(crh_index *h, int64_t n, const float *vecs, int on_device,
                                   const int32_t *codes, int64_t *first_row_out, void *stream);
 
-/* Mark rows deleted (they stop matching; space is not reclaimed).  rows: host int64[n].
+/* Mark rows deleted (they stop matching; the space comes back with crh_index_compact).  rows: host int64[n].
  * Replaces the point-removal half of QdrantManager.delete (embeddings/client.py:159-169);
  * which rows a payload filter selects is resolved by the host-side payload table. */
 int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows);
@@ -108,6 +108,16 @@ int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows);
  * n_cleared_out receives how many.  Replaces QdrantManager.delete -> client.delete(FilterSelector(filter))
  * (embeddings/client.py:159-169) without resolving the filter to row numbers on the host. */
 int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_filters, int64_t *n_cleared_out);
+
+/* Reclaim the rows of deleted points -- what Qdrant's optimizer does when it vacuums a segment.  The reference's indexing
+ * flow deletes and re-inserts every chunk of a file on every run (embeddings/indexer.py:61-64, called with force=True from
+ * pipeline/orchestrator.py:630-650), so without this the scan streams one more corpus of dead rows per re-index.
+ * Device-side stable compaction of everything stored per row (the tiled bf16 image, the f32 master, the code columns): the
+ * alive rows move down in their old order, so row numbers stay ascending in insertion order and ties keep "lower row first";
+ * afterwards count == alive and the scan reads only live tiles.  old_to_new_host (may be NULL): int64 per OLD row, its new
+ * row number or -1 for a deleted one -- what the caller's host tables (ids, payloads, side columns) are remapped with.
+ * rows_after (may be NULL) receives the new row count.  Capacity is unchanged. */
+int crh_index_compact(crh_index *h, int64_t *old_to_new_host, int64_t *rows_after);
 
 /* Snapshot support -- what Qdrant's on-disk volume does for the reference (docker-compose.yml:42-43): the stored image moves
  * VERBATIM between HBM and host buffers (typically an mmap of a file) in chunks of 32-row tiles, so a restored index answers
@@ -156,22 +166,6 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
 
 /* Completes every crh_search enqueued with device outputs since the last finish. */
 int crh_search_finish(crh_index *h, void *stream);
-
-/* Overlapped searches (throughput serving; no reference counterpart -- the reference issues one blocking RPC per query,
- * embeddings/client.py:142-148).  While enabled, crh_search calls with device-resident queries AND outputs run their batches
- * in turn in internal lanes (enable = 1: four; enable = n > 1: n, at most 8), each on its own stream, their main scans back to
- * back on one more: a batch starts after everything the caller had enqueued on
- * `stream` at the call, but `stream` does NOT wait for it -- so the next batch's query preparation, seed scan and threshold
- * kernels run beside the previous batch's final selection instead of behind it.  The outputs of ALL such calls are complete,
- * in `stream` order, only after crh_search_finish(h, stream) (or any other entry point of this index on `stream`, or disabling
- * the mode); until then the caller must not read or reuse them, and results are bit-identical to serial searches.
- * Calls with a host-side query or output buffer are unaffected (they join first and complete before returning). */
-int crh_index_set_overlap(crh_index *h, int enable, void *stream);
-/* Makes `stream` wait (on the device; the host does not block) for the overlapped searches in flight: all of them, or all
- * but the `keep_last` batches enqueued last (a batch = one scan pass: up to 64 queries, or up to 256 of a longer call) -- the
- * form a pipelined caller uses: search(i+1); search(i+2); join(keep_last = 2); consume results i on `stream` (e.g. the all-gather + crh_merge_topk of a row-sharded search).  Candidate-buffer overflow
- * is still only detected and repaired by crh_search_finish. */
-int crh_search_join(crh_index *h, void *stream, int keep_last);
 
 int crh_search_get_stats(crh_index *h, crh_search_stats *out);
 
@@ -287,17 +281,25 @@ int crh_masked_mean_pool(const void *tok, const uint64_t *kmask, float *sent, in
                          void *stream);
 
 /* Packed rows: the same three kernels on a batch WITHOUT padding.  Row b of the batch is the tokens
- * [row_off[b], row_off[b+1]) of one flat token axis (ids int32 [T], activations [T, ...], T = row_off[B]); Lmax (a multiple of
+ * [row_off[b], row_off[b+1]) of one flat token axis of T tokens (ids int32 [T], activations [T, ...]); Lmax (a multiple of
  * 16, >= every row's length, <= 512) sizes the key-mask stride (ceil(Lmax/64) words per row) and the launch.  The GEMM /
  * LayerNorm entry points above take T tokens as they are.  What it buys: the padded form rounds every row up to its bucket's
- * length (a multiple of 16) -- ~4 % of the tokens of a mean-200 mix -- and every kernel of the forward pays for them. */
+ * length (a multiple of 16) -- ~4 % of the tokens of a mean-200 mix -- and every kernel of the forward pays for them.
+ * row_off lives on the device, so the library cannot look at it when a call is made: every kernel CLAMPS what it reads from
+ * it to the T tokens the buffers hold (a bad offsets array can produce wrong rows, never an access outside the buffers), and
+ * crh_embed_ln_packed -- the first call of a forward -- also launches a check of the whole array (row_off[0] == 0,
+ * non-decreasing, every row <= Lmax, row_off[B] == T) whose verdict is reported as CRH_E_INVALID by the next packed entry
+ * point called after the check has run, and in any case by crh_encoder_finish. */
 int crh_embed_ln_packed(const int32_t *ids, const int32_t *row_off, const void *word, const void *pos, const void *type0,
                         const float *gamma, const float *beta, float eps, int pad_id, void *out, uint64_t *kmask, int B,
-                        int Lmax, int D, void *stream);
-int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int Lmax, int H,
-                        void *stream);
-int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int Lmax,
-                                int D, void *stream);
+                        int T, int Lmax, int D, void *stream);
+int crh_attn_fwd_packed(const void *qkv, const int32_t *row_off, const uint64_t *kmask, void *out, int B, int T, int Lmax,
+                        int H, void *stream);
+int crh_masked_mean_pool_packed(const void *tok, const int32_t *row_off, const uint64_t *kmask, float *sent, int B, int T,
+                                int Lmax, int D, void *stream);
+/* Waits for `stream` and returns the verdict of the device-side checks of the packed entry points launched on this device
+ * since the last call (CRH_OK, or CRH_E_INVALID with the reason in crh_last_error) -- the sync point of a forward. */
+int crh_encoder_finish(void *stream);
 
 /* ------------------------------------------------------------- debug build only --------- */
 /* Exported ONLY by libcoderag_hip_debug.so (code-rag_amd/build.sh compiles the same sources a second time with

@@ -485,112 +485,3 @@ def test_wide_scan_equals_the_64_query_passes_and_survives_overflow(gpu, monkeyp
     assert np.array_equal(fr, wr) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
     wide.close()
     narrow.close()
-
-
-def test_ring_scan_equals_the_streaming_scan(gpu, monkeypatch):
-    """k_scan_ring (corpus through the LDS-DMA ring, K split over wave pairs, half-tile seeding) and k_scan (corpus straight
-    into registers) nominate differently; the canonical re-score decides both: identical bytes -- also with a filter,
-    tombstones, a short batch (one query block), k beyond the row count, and through the regrow path."""
-    ffi = _ffi()
-    rng = np.random.default_rng(99)
-    n = 70001
-    x = rng.standard_normal((n, D), dtype=np.float32)
-    x[500:900] = x[3] + 1e-3 * rng.standard_normal((400, D), dtype=np.float32)
-    codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
-    q = rng.standard_normal((64, D), dtype=np.float32)
-    q[5] = x[3]
-    dead = rng.choice(n, 5000, replace=False)
-    res = {}
-    for mode in ("ring", "stream"):
-        monkeypatch.setenv("CODERAG_HIP_SCAN", mode)
-        idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n, n_code_cols=1)
-        idx.append(x, codes)
-        idx.tombstone(dead)
-        out = [idx.search(q, 100), idx.search(q[:7], 10, filters=[(0, 1)]), idx.search(q[:33], 1000), idx.search(q[:1], 5)]
-        idx.set_tuning(force_fallback=1)
-        out.append(idx.search(q, 100))
-        assert idx.stats()["fallback_used"] == 1
-        res[mode] = out
-        idx.close()
-    monkeypatch.delenv("CODERAG_HIP_SCAN")
-    for a, b in zip(res["ring"], res["stream"]):
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    assert np.array_equal(res["ring"][0][1], res["ring"][4][1])
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-def test_overlapped_searches_equal_the_oracle_and_the_serial_calls(gpu, bf16):
-    """crh_index_set_overlap: consecutive device-to-device searches run in two lanes on their own streams; every result must be
-    the oracle's, bit for bit -- with filters (the mask lives in the lane), a 300-query call (wide passes in both lanes), an
-    append and a tombstone in between (both join the lanes first), and the overflow fallback (re-run at finish)."""
-    import torch
-    ffi = _ffi()
-    dev = torch.device("cuda:0")
-    n, k = 30_000, 100
-    x = _corpus(n, 71)
-    codes = (np.arange(n) % 3).astype(np.int32).reshape(-1, 1)
-    idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n + 64, n_code_cols=1)
-    idx.append(x[: n - 500], codes[: n - 500])
-    st = torch.cuda.current_stream().cuda_stream
-    idx.set_overlap(True, st)
-    jobs = []          # (queries, filters, oracle filters, rows visible, alive)
-
-    def launch(q, filters=None, rows=n - 500, alive=None):
-        qd = torch.from_numpy(q).to(dev)
-        s = torch.empty((len(q), k), dtype=torch.float32, device=dev)
-        r = torch.empty((len(q), k), dtype=torch.int64, device=dev)
-        idx.search(qd, k, filters=filters, out_scores=s, out_rows=r, stream=st)
-        jobs.append((q, qd, s, r, filters, rows, None if alive is None else alive.copy()))
-
-    for i in range(5):
-        launch(_corpus(64 if i != 2 else 17, 100 + i))
-    launch(_corpus(64, 110), filters=[(0, 1)])
-    launch(_corpus(64, 111), filters=[(0, 2)])
-    launch(_corpus(300, 112))
-    idx.append(x[n - 500:], codes[n - 500:], stream=st)             # joins, then grows the corpus
-    launch(_corpus(64, 113), rows=n)
-    alive = np.ones(n, np.uint8)
-    dead = np.arange(0, n, 7)
-    idx.tombstone(dead)                                            # joins too
-    alive[dead] = 0
-    launch(_corpus(64, 114), rows=n, alive=alive)
-    launch(_corpus(33, 115), filters=[(0, 0)], rows=n, alive=alive)
-    idx.search_finish(st)
-    torch.cuda.synchronize()
-    assert idx.stats()["fallback_used"] == 0
-    for q, _, s, r, filters, rows, al in jobs:
-        es, er = orc.cosine_search(x[:rows], q, k, bf16=bf16, alive=al, codes=codes[:rows] if filters else None,
-                                   filters=filters)
-        assert np.array_equal(r.cpu().numpy(), er), (len(q), filters, rows)
-        assert np.array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
-    # the overflow fallback under overlap: tiny candidate buffers, results repaired at finish
-    idx.set_tuning(force_fallback=1)
-    jobs.clear()
-    for i in range(3):
-        launch(_corpus(64, 120 + i), rows=n, alive=alive)
-    idx.search_finish(st)
-    torch.cuda.synchronize()
-    assert idx.stats()["fallback_used"] == 1
-    for q, _, s, r, filters, rows, al in jobs:
-        es, er = orc.cosine_search(x, q, k, bf16=bf16, alive=al)
-        assert np.array_equal(r.cpu().numpy(), er) and np.array_equal(s.cpu().numpy().view(np.uint32), es.view(np.uint32))
-    idx.set_tuning(force_fallback=0)
-    # the pipelined consumer: search(i+2); join all but the last two batches; read batch i on the caller's stream
-    jobs.clear()
-    taken = []
-    launch(_corpus(64, 130), rows=n, alive=alive)
-    launch(_corpus(64, 131), rows=n, alive=alive)
-    for i in range(6):
-        if i + 2 < 6:
-            launch(_corpus(64, 132 + i), rows=n, alive=alive)
-        idx.search_join(st, keep_last=min(2, 5 - i))
-        taken.append((jobs[i][2].clone(), jobs[i][3].clone()))     # torch's current stream is `st`
-    idx.search_finish(st)
-    torch.cuda.synchronize()
-    for (q, _, s, r, filters, rows, al), (ts, tr) in zip(jobs, taken):
-        es, er = orc.cosine_search(x, q, k, bf16=bf16, alive=al)
-        assert np.array_equal(tr.cpu().numpy(), er) and np.array_equal(ts.cpu().numpy().view(np.uint32), es.view(np.uint32))
-    idx.set_overlap(False, st)
-    s0, r0 = idx.search(jobs[0][0], k)                              # serial host-buffer call after the mode is left
-    assert np.array_equal(r0, jobs[0][3].cpu().numpy())
-    idx.close()
