@@ -12,11 +12,13 @@ over all ranks, i.e. row.query pairs/s / 1e7.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...    (the same thing, launched outside)
 
 Prints ONE JSON line (rank 0).  Beside the headline it carries sub-records, each with its own roofline / parity block:
-`filtered`, `config5` (scan + side-column gather + device hybrid re-rank, checked against the host HybridRanker in-run),
-`f32_store` (ids and scores bit-exact vs the f32 oracle), `embed` (BASELINE configs[1]), `embed_e2e` (texts -> provider ->
-python float lists), `c1` (BASELINE configs[0] shape: ~1k code chunks through the reference-shaped surfaces, GPU vs the CPU
-oracle), `cpu_baseline`.  No reference code or CPU path is inside a timed GPU region; the CPU legs (oracle = test
-infrastructure) run afterwards on rank 0 at N=1 only.
+`filtered`, `wide` (one 512-query call), `config5` (scan + side-column gather + device hybrid re-rank, checked against the host
+HybridRanker in-run), `f32_store` (ids and scores bit-exact vs the f32 oracle), `embed` (BASELINE configs[1], encoder only),
+`c2` (configs[1] as one pipeline: 100k chunks -> packed encoder -> device-to-device index -> top-100 over the EMBEDDED vectors,
+bit-exact vs the oracle on those vectors, and end-to-end recall against the fp32 pipeline on two weight statistics),
+`embed_e2e` (texts -> provider -> python float lists), `c1` (BASELINE configs[0] shape: ~1k code chunks through the
+reference-shaped surfaces, GPU vs the CPU oracle), `cpu_baseline`.  No reference code or CPU path is inside a timed GPU
+region; the CPU legs (oracle = test infrastructure) run afterwards on rank 0 at N=1 only.
 
 `--backend gloo` is the launcher rehearsal for machines without a GPU (tests/test_bench_launch.py): the same self-launch,
 rendezvous, exchange-record all-gather, max-over-ranks timing and JSON assembly, with NO device work and `value` null.
@@ -36,7 +38,7 @@ _T0 = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-ALL_LEGS = ("filtered", "wide", "config5", "f32_store", "embed", "embed_e2e", "c1", "cpu")
+ALL_LEGS = ("filtered", "wide", "config5", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
 
 
 def log(msg: str) -> None:
@@ -87,6 +89,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--embed-chunks", type=int, default=100000, help="synthetic chunks for the encoder leg (BASELINE configs[1]: 100k synthetic code chunks)")
     ap.add_argument("--e2e-texts", type=int, default=20000, help="texts of the embed_e2e leg")
+    ap.add_argument("--c2-parity-chunks", type=int, default=2000, help="chunks of the c2 leg's end-to-end recall subsample (per weight statistic)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rows per GPU (BASELINE C4a); strong: --rows in total, split over the ranks (C4b)")
     ap.add_argument("--check-rows", type=int, default=200_000, help="rows of the parity subsample checked vs the oracle")
@@ -331,7 +334,7 @@ def run(args, json_fd) -> None:
     if args.no_cpu_baseline or world > 1:
         legs -= {"cpu"}
     if world > 1:
-        legs -= {"c1", "embed_e2e", "f32_store", "filtered", "wide"}      # one-GPU verification legs
+        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "wide"}      # one-GPU verification legs
 
     D, N, B, K = 768, args.rows, args.queries, args.k
     if args.scaling == "strong":
@@ -561,6 +564,9 @@ def run(args, json_fd) -> None:
         legs.discard("embed")
     leg("embed", embed_leg, np, torch, local_rank, args.embed_chunks, rank, world, dist,
         ("cpu" in legs), args.cpu_seconds)
+    if args.embed_chunks <= 0:
+        legs.discard("c2")
+    leg("c2", c2_leg, np, torch, ffi, local_rank, args.embed_chunks, rank, B, K, args.c2_parity_chunks)
     ckpt = {}
     leg("embed_e2e", embed_e2e_leg, np, torch, local_rank, args.e2e_texts, ckpt)
     leg("c1", c1_leg, np, torch, local_rank, ckpt, args.cpu_seconds * 4 if "cpu" in legs else 0.0)
@@ -707,8 +713,7 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
     # packed batches (no padding: rows back to back on one token axis, attention / gather / pool take the row offsets):
     # what HipUniXcoder.embed_ids / embed_bodies submit; the ids are staged on the device before the timed region
     batches = []
-    id_rows = [np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, int(n) - 4), [2]]).astype(np.int32) if n >= 4
-               else np.asarray([0, 5, 2, 2][:int(n)], np.int32) for n in lengths]
+    id_rows = synth_chunk_ids(np, cfg, lengths, rng)
     for rows, _ in model.plan_batches(lengths, max_tokens=65536, max_rows=4096, packed=True):
         flat, off, Lmax = model.pack_rows(id_rows, rows)
         batches.append((torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), Lmax))
@@ -758,6 +763,152 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
         res["cpu_baseline"] = {"value": done / cdt, "unit": "chunks/s", "cores": host_threads(), "kind": "port",
                                "sample": f"oracle/encoder.py torch-fp32 forward, {done} single-text calls "
                                          f"(mean {toks / max(1, done):.0f} tokens), {cdt:.1f} s"}
+    return res
+
+
+def synth_chunk_ids(np, cfg, lengths, rng):
+    """Token-id rows shaped like UniXcoder.tokenize output (unixcoder_provider.py:108-122): [<s>, <encoder-only>, </s>] + body + [</s>],
+    body uniform over the vocabulary above the specials (SURVEY.md section 8d, C2 inputs)."""
+    return [np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, int(n) - 4), [2]]).astype(np.int32) if n >= 4
+            else np.asarray([0, 5, 2, 2][:int(n)], np.int32) for n in lengths]
+
+
+def c2_leg(np, torch, ffi, local_rank, n_chunks, rank, B, K, parity_chunks):
+    """BASELINE configs[1] as the ONE pipeline it names: n synthetic code chunks (the embed leg's seed and length mix) -> packed
+    HIP encoder -> device-to-device crh_index_append -> batch-64 exact top-100 over the EMBEDDED vectors (the reference's
+    embeddings/indexer.py:66-85 + query/vector_search.py:60-116 with the host round trips taken out).  Encoder outputs are
+    anisotropic -- a large common component, tightly packed cosines -- which is where the scan's threshold / margin /
+    candidate-buffer logic is least like the Gaussian corpus of the headline: `search_stats` reports what it did there, and
+    ids + f32 score bits are compared with oracle/search on those same vectors (both stores).  Then, for a subsample and BOTH
+    weight statistics (the deliberately sharp ones and HF-init ones), the whole GPU pipeline (bf16 encoder, bf16 store)
+    against the fp32 pipeline (oracle encoder in fp32 + oracle f32 search): recall@100 / recall@10 / top-1."""
+    from coderag_amd import encoder as drv
+    from oracle import encoder as oenc
+    from oracle import search as osr
+    cfg = drv.EncoderConfig()
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(1234 + rank)
+    lengths = np.clip(np.round(np.exp(rng.normal(np.log(160.0), 0.8, n_chunks))), 8, 512).astype(np.int64)
+    id_rows = synth_chunk_ids(np, cfg, lengths, rng)
+    qrng = np.random.default_rng(4321)
+    qlens = np.clip(np.round(np.exp(qrng.normal(np.log(40.0), 0.6, B))), 8, 512).astype(np.int64)      # queries are shorter than chunks
+    q_rows = synth_chunk_ids(np, cfg, qlens, qrng)
+    for i in range(min(B // 2, n_chunks)):            # half the queries are a corpus chunk with a tenth of its tokens replaced: a near neighbour exists
+        row = id_rows[i].copy()
+        if len(row) > 8:
+            swap = qrng.choice(np.arange(3, len(row) - 1), max(1, (len(row) - 4) // 10), replace=False)
+            row[swap] = qrng.integers(16, cfg.vocab_size, len(swap))
+        q_rows[i] = row
+
+    def build(init):
+        return drv.HipUniXcoder(drv.synthetic_weights(cfg, 23, init=init), cfg, drv.HashTokenizer(cfg.vocab_size), local_rank)
+    model = build("sharp")
+    plan = model.plan_batches(lengths, max_tokens=65536, max_rows=4096, packed=True)
+    batches = []
+    for rows, _ in plan:
+        flat, off, Lmax = model.pack_rows(id_rows, rows)
+        batches.append((torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), Lmax, len(rows)))
+    order = np.concatenate([np.asarray(rows, np.int64) for rows, _ in plan])        # index row r holds chunk order[r]
+    codes = torch.zeros((max(b[3] for b in batches), 1), dtype=torch.int32, device=dev)
+    res = {"workload": f"{n_chunks} synthetic code chunks (mean {lengths.mean():.0f} tokens) -> packed HIP encoder -> device-to-device "
+                       f"crh_index_append -> batch-{B} exact top-{K} over the {n_chunks} embedded vectors",
+           "data": "synthetic ids + seeded random RoBERTa-base-geometry weights (no checkpoint offline); queries: 32 corpus chunks with 10 % of "
+                   "their tokens replaced + 32 fresh rows"}
+    stores = {}
+    for name, dtype in (("bf16", ffi.DTYPE_BF16), ("f32", ffi.DTYPE_F32)):
+        idx = ffi.Index(768, dtype, capacity_rows=n_chunks, n_code_cols=1, device=local_rank)
+        for ids, off, Lmax, nr in batches[:2]:
+            model.forward_packed(ids, off, Lmax)
+        torch.cuda.synchronize()
+        outs = []
+        t0 = time.perf_counter()
+        for ids, off, Lmax, nr in batches:
+            out = model.forward_packed(ids, off, Lmax)
+            idx.append(out, codes=codes[:nr], stream=stream)           # device to device, on the forward's stream
+            outs.append(out)
+        torch.cuda.synchronize()
+        t_index = time.perf_counter() - t0
+        qd = model.embed_ids([r.tolist() for r in q_rows])
+        r = timed_search(torch, idx, qd, K, None, 20, 3, stream)
+        vecs = torch.cat(outs).cpu().numpy()
+        qh = qd.cpu().numpy()
+        es, er = osr.cosine_search(vecs, qh, K, bf16=(name == "bf16"))
+        gs, gr = r["scores"].cpu().numpy(), r["rows"].cpu().numpy()
+        stores[name] = {"ids_bit_exact": bool(np.array_equal(gr, er)), "scores_bit_exact": bool(np.array_equal(gs.view(np.uint32), es.view(np.uint32))),
+                        "search_ms_per_batch": r["ms_per_step"], "search_stats": r["stats"], "scan_ms": r["scan_ms"],
+                        "chunks_per_s_embed_plus_index": n_chunks / t_index}
+        if name == "bf16":
+            # how unlike the Gaussian corpus these vectors are: the common component and the spread of the top-100 scores
+            vn = vecs / np.linalg.norm(vecs, axis=1, keepdims=True)
+            mean_dir = vn.mean(0)
+            res.update({"value": n_chunks / t_index, "unit": "chunks/s (embed + index, device to device)", "seconds_embed_plus_index": t_index,
+                        "search": {"ms_per_batch": r["ms_per_step"], "queries_per_s": B / (r["ms_per_step"] * 1e-3), "step_ms_device": r["step_ms_device"]},
+                        "search_stats": r["stats"],
+                        "embedding_geometry": {"norm_of_mean_unit_vector": float(np.linalg.norm(mean_dir)),
+                                               "top1_score_median": float(np.median(gs[:, 0])), "top100_score_median": float(np.median(gs[:, K - 1])),
+                                               "top1_minus_top100_median": float(np.median(gs[:, 0] - gs[:, K - 1]))}})
+            res["perturbed_chunk_queries_find_their_chunk_top1"] = float(np.mean([order[gr[i, 0]] == i for i in range(min(B // 2, n_chunks))]))
+        idx.close()
+        del outs, vecs
+    res["parity"] = {"what": "ids and f32 score bits of the HIP search vs oracle/search on the SAME embedded vectors, all rows", **{f"{k}_store": v for k, v in stores.items()}}
+    log(f"c2: {res['value']:.0f} chunks/s embed+index, search {res['search']['ms_per_batch']:.3f} ms/batch, "
+        f"bit-exact bf16 {stores['bf16']['ids_bit_exact'] and stores['bf16']['scores_bit_exact']} f32 {stores['f32']['ids_bit_exact'] and stores['f32']['scores_bit_exact']}")
+
+    # ---- end to end: GPU pipeline (bf16 encoder -> bf16 store -> HIP top-k) vs the fp32 pipeline (oracle encoder fp32 -> oracle f32 search)
+    m = int(min(parity_chunks, n_chunks))
+    e2e = {}
+    if m > 0:
+        sub = [id_rows[i] for i in range(m)]
+        ocfg = oenc.EncoderConfig()
+        kk = min(K, m)
+
+        def oracle_embed(W, rows):      # fp32 torch graph of oracle/encoder.py evaluated on the GPU (device="cuda": see its docstring)
+            out = np.empty((len(rows), 768), np.float32)
+            idxs = np.argsort([len(r) for r in rows], kind="stable")
+            for b0 in range(0, len(rows), 32):
+                part = idxs[b0:b0 + 32]
+                L = max(len(rows[i]) for i in part)
+                ids = np.full((len(part), L), ocfg.pad_token_id, np.int64)
+                for r_, i in enumerate(part):
+                    ids[r_, : len(rows[i])] = rows[i]
+                out[part] = oenc.forward(W, ocfg, ids, device=str(dev))
+            return out
+        for label, init in (("sharp", "sharp"), ("hfinit", "hf")):
+            mdl = model if init == "sharp" else build(init)
+            W = oenc.to_device(oenc.random_weights(ocfg, 23, init=init), str(dev))
+            g_c = mdl.embed_ids([r.tolist() for r in sub])
+            g_q = mdl.embed_ids([r.tolist() for r in q_rows])
+            idx = ffi.Index(768, ffi.DTYPE_BF16, capacity_rows=m, device=local_rank)
+            idx.append(g_c, stream=stream)
+            gs, gr = idx.search(g_q.cpu().numpy(), kk)
+            idx.close()
+            o_c, o_q = oracle_embed(W, sub), oracle_embed(W, q_rows)
+            ors, orr = osr.cosine_search(o_c, o_q, kk, bf16=False)
+            gc = g_c.cpu().numpy()
+            cos = np.sum(gc * o_c, 1) / (np.linalg.norm(gc, axis=1) * np.linalg.norm(o_c, axis=1))
+            # north_star's bf16 criterion is a SCORE criterion ("within 1e-3 cosine score in bf16"): encoder outputs pack their
+            # cosines tightly (the top-100 of a query span a few 1e-2), so ids near the cut-off swap on differences far below
+            # it.  A returned id counts as right-within-eps when the fp32 pipeline scores it within eps of ITS k-th score.
+            ref_all = osr.preprocess(o_q) @ osr.preprocess(o_c).T
+            got_ref_scores = np.take_along_axis(ref_all, np.maximum(gr, 0), axis=1)
+            within = {eps: float(np.mean(got_ref_scores >= ors[:, kk - 1:kk] - eps)) for eps in (1e-3, 1e-4)}
+            by_rank = float(np.max(np.abs(gs - ors)))
+
+            def rec(a, b, n):
+                return float(np.mean([len(set(x[:n].tolist()) & set(y[:n].tolist())) / n for x, y in zip(a, b)]))
+            e2e[label] = {"chunks": m, "queries": int(len(q_rows)), f"recall_at_{kk}": rec(gr, orr, kk), "recall_at_10": rec(gr, orr, min(10, kk)),
+                          "top1_agreement": float(np.mean(gr[:, 0] == orr[:, 0])), "min_cosine_gpu_vs_fp32": float(cos.min()),
+                          "mean_cosine_gpu_vs_fp32": float(cos.mean()),
+                          f"recall_at_{kk}_within_1e-3_of_the_fp32_kth_score": within[1e-3], f"recall_at_{kk}_within_1e-4": within[1e-4],
+                          "max_abs_score_difference_by_rank": by_rank,
+                          "fp32_top1_minus_topk_score_median": float(np.median(ors[:, 0] - ors[:, kk - 1]))}
+            log(f"c2 end-to-end [{label}]: recall@{kk} {e2e[label][f'recall_at_{kk}']:.4f} (within 1e-3 of the fp32 k-th score: {within[1e-3]:.4f}), "
+                f"recall@10 {e2e[label]['recall_at_10']:.4f}, top-1 {e2e[label]['top1_agreement']:.3f}, min cos {cos.min():.6f}, score diff by rank {by_rank:.2e}")
+            del W, mdl
+            torch.cuda.empty_cache()
+    res["end_to_end_vs_fp32_pipeline"] = dict(e2e, what="GPU: bf16 HIP encoder -> bf16 HIP store -> crh_search; reference side: oracle/encoder.py in fp32 "
+                                              "(torch fp32 on the GPU for speed; pinned to its CPU evaluation by tests/test_c2_gpu.py) -> oracle f32 cosine search")
     return res
 
 

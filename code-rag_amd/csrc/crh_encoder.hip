@@ -794,98 +794,14 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
     *reinterpret_cast<float2 *>(sent + (size_t)b * D + d) = float2{s0 / (float)cnt, s1 / (float)cnt};
 }
 
-// ------------------------------------------------------------------ skinny GEMM (a handful of rows)
-//
-// One short query is 32-64 tokens: the tiled kernels above would run one 256-row tile per column block with a handful of
-// rows in it, ~15 us per call, 48 calls per forward.  Here a workgroup owns 16 output columns and a slab of <= 64 rows; its four
-// waves split K, every lane fetches its MFMA operand pieces straight from global memory (16 bytes of one W row / one A
-// row per k-step of 32: no LDS staging, the whole W matrix is read exactly once across the grid), the four partial
-// accumulators meet in LDS and wave w finishes 16-row block w.  C^T fragments as everywhere: a lane ends up with 4
-// consecutive n of one row m.  N % 16 == 0, K % 128 == 0.
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ C, int M, int N, int K)
-{
-    __shared__ f32x4 part[4][4][64];   // [wave][m-block][lane]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    // blockIdx.y selects a slab of 64 rows (each slab re-reads W)
-    const int row0 = blockIdx.y * 64;
-    A += (size_t)row0 * K;
-    C += (size_t)row0 * N;
-    if (EPI == 2) R += (size_t)row0 * N;
-    M = (M - row0) < 64 ? (M - row0) : 64;
-    const int MB = (M + 15) >> 4;      // 1..4
-    const int kspan = K >> 2, k0 = wave * kspan;
-    const bf16_t *wp = W + (size_t)(n0 + r16) * K + k0 + kq * 8;
-    const bf16_t *ap[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        int m = mb * 16 + r16;
-        m = m < M ? m : M - 1;          // rows past M: a valid row, result never stored
-        ap[mb] = A + (size_t)m * K + k0 + kq * 8;
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < kspan; s0 += 192) {      // 6 k-steps of 32 per round (K = 768: one round per wave)
-        bf16x8 wf[6], af[4][6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const bool on = s0 + s * 32 < kspan;
-            wf[s] = on ? *reinterpret_cast<const bf16x8 *>(wp + s0 + s * 32) : bf16x8{};
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                af[mb][s] = (on && mb < MB) ? *reinterpret_cast<const bf16x8 *>(ap[mb] + s0 + s * 32) : bf16x8{};
-        }
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                if (mb < MB) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[mb][s], acc[mb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) part[wave][mb][lane] = acc[mb];
-    __syncthreads();
-    if (wave >= MB) return;
-    const int mb = wave;
-    f32x4 v = part[0][mb][lane];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) v += part[w][mb][lane];
-    // v[j] = C[mb*16 + r16][n0 + 4*kq + j]
-    const int m = mb * 16 + r16, n = n0 + 4 * kq;
-    const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
-    float o0 = v[0] + b4.x, o1 = v[1] + b4.y, o2 = v[2] + b4.z, o3 = v[3] + b4.w;
-    if (EPI == 1) {
-        const f32x2_t ga = gelu_erf2(f32x2_t{o0, o1}), gb = gelu_erf2(f32x2_t{o2, o3});
-        o0 = ga.x;
-        o1 = ga.y;
-        o2 = gb.x;
-        o3 = gb.y;
-    }
-    if (m >= M) return;
-    if (EPI == 2) {
-        const u32x2 r2 = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
-        o0 += bf2f(r2.x & 0xffffu);
-        o1 += bf2f(r2.x >> 16);
-        o2 += bf2f(r2.y & 0xffffu);
-        o3 += bf2f(r2.y >> 16);
-    }
-    u32x2 o;
-    o.x = pack2(o0, o1);
-    o.y = pack2(o2, o3);
-    *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
-}
-
 // ------------------------------------------------------------------ mid-size GEMM (512 < T <= a few thousand rows)
 //
-// Between the query path and the big index-time batches the 256-row tiles run out of parallelism: at T = 2048 the N = 768
+// From one query up to a few thousand rows the 256-row tiles run out of parallelism: at T = 2048 the N = 768
 // GEMMs are 48 workgroups on 256 CUs, each walking its whole K in series with every LDS-DMA exposed to the full HBM/MALL
 // latency (measured 1.1 us per k-step against 0.45 in steady state; 34 us per call, 54 % of the forward).  What is missing
 // there is bytes in flight, not MFMA rate -- so: 64 x 64 tiles (8x the workgroups), two workgroups per CU, a 4-stage ring
 // with three k-steps in flight per workgroup, and one raw barrier per step.  Staging, swizzle and the C^T fragment layout
-// are k_gemm_nt's.  (A first version fetched MFMA operands straight from global memory, like k_gemm_skinny: a wave's
+// are k_gemm_nt's.  (A first version fetched MFMA operands straight from global memory: a wave's
 // 16-byte pieces of 16 different rows cost the texture path one cache line each, and it stalled at ~260 TFLOP/s whatever
 // the size -- LDS-DMA moves 8 full 128-byte rows per instruction.)  N % 64 == 0, K % 64 == 0.
 template <int EPI>
@@ -1022,22 +938,6 @@ unsigned gemm_grid(int T, int N)
     return xcd_grid(crh::ceil_div(T, BM), N / BN, persistent ? crh::current_device_cus() / 8 : INT32_MAX);
 }
 
-// T <= 16 rows (one very short query): k_gemm_skinny; from 17 rows on k_gemm_mid is faster (tools/enc_mid_bench.py: one
-// text of 64 tokens 0.53 vs 0.70 ms, 256 tokens 0.68 vs 1.03).  CODERAG_HIP_SKINNY=0 turns it off, CODERAG_HIP_SKINNY_MAX_T moves the edge
-bool use_skinny(int T, int N, int K)
-{
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("CODERAG_HIP_SKINNY");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    static int tmax = 0;
-    if (!tmax) {
-        const char *e = getenv("CODERAG_HIP_SKINNY_MAX_T");
-        tmax = e ? atoi(e) : 16;
-    }
-    return on && T <= tmax && N % 16 == 0 && K % 128 == 0;
-}
 template <int EPI>
 int launch_mid(const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
 {
@@ -1047,7 +947,7 @@ int launch_mid(const void *x, const void *w, const float *bias, const void *res,
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
-// ---- which tiled kernel?  Above the skinny range three kernels compete and the winner flips with the shape (measured per
+// ---- which tiled kernel?  Three kernels compete and the winner flips with the shape (measured per
 // GEMM, tools/gemm_mid_sweep.py): a launch costs (rounds of its busiest XCD label) x (one tile's walk through K), so
 // k_gemm_nt wins while its 256x128 tiles fill the chip in one round, the 256x256 ping-pong kernel wherever halving the
 // tile count saves a round (and everywhere at scale), k_gemm_mid while both leave most CUs idle.  The constants are fits
@@ -1130,14 +1030,6 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
     if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
     if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm: act=%d (0 none, 1 gelu)", act);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (use_skinny(T, N, K)) {
-        if (act == 1)
-            hipLaunchKernelGGL((k_gemm_skinny<1>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
-        else
-            hipLaunchKernelGGL((k_gemm_skinny<0>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    }
     const GemmKernel which = choose_gemm(T, N, K, act);
     if (which == GEMM_MID) return act == 1 ? launch_mid<1>(x, w, bias, nullptr, y, T, N, K, st) : launch_mid<0>(x, w, bias, nullptr, y, T, N, K, st);
     if (which == GEMM_PP) return launch_gemm256(act, x, w, bias, nullptr, y, T, N, K, st);
@@ -1244,15 +1136,7 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     // (y == residual with K <= 1024 cannot take the first form -- the GEMM would overwrite the residual -- and falls to the second.)
     const bool ln_side = K <= 1024 && y != residual;
     const int epi = ln_side ? 0 : 2;
-    if (use_skinny(T, N, K) && y != residual) {
-        if (epi == 2)
-            hipLaunchKernelGGL((k_gemm_skinny<2>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)residual, (bf16_t *)y, T, N, K);
-        else
-            hipLaunchKernelGGL((k_gemm_skinny<0>), dim3(N / 16, (T + 63) / 64), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
-        CRH_HIP(hipGetLastError());
-    } else {
-        CRH_TRY(launch_tiled(epi, x, w, bias, residual, y, T, N, K, st));
-    }
+    CRH_TRY(launch_tiled(epi, x, w, bias, residual, y, T, N, K, st));
     if (ln_side)
         hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
     else

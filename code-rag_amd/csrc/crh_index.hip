@@ -198,7 +198,7 @@ __global__ void k_fill_pad(float *s, int64_t *r, int64_t n)
 
 int build_mask(crh_index *h, crh_index::Workspace &w, const crh_filter *filters, int nfilt, const uint32_t **mask_out, hipStream_t st)
 {
-    if (nfilt == 0) {
+    if (nfilt == 0 || h->count == 0) {   // (an empty index: nothing to mask, and a zero-block launch is an error)
         *mask_out = h->alive;
         return CRH_OK;
     }

@@ -52,14 +52,16 @@ class SideColumns:
 
     INT_COLS = ("content_len", "degree", "file_code", "key_code", "node_code", "name_len")
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, books: dict[str, dict[str, int]] | None = None):
         import torch
         self._torch = torch
         self.device = torch.device("cuda", device)
         self.rows = 0
         self._host: dict[str, np.ndarray] = {c: np.zeros((0,), np.int32) for c in self.INT_COLS}
         self._names = np.zeros((0, ffi.RR_NAME_BYTES), np.uint8)
-        self._books: dict[str, dict[str, int]] = {"file": {}, "key": {}, "node": {}}
+        # value -> code dictionaries of file path / merge key / centrality key; the shards of one collection SHARE them
+        # (candidates of different shards are compared by code)
+        self._books: dict[str, dict[str, int]] = books if books is not None else {"file": {}, "key": {}, "node": {}}
         self._node_keys: list[str] = []
         self._dev: dict[str, Any] | None = None      # device tensors with capacity >= rows
         self._dev_rows = 0                           # rows already uploaded
@@ -106,6 +108,18 @@ class SideColumns:
             if name:
                 self._names[r, : min(len(name), width)] = np.frombuffer(name[:width], dtype=np.uint8)
         self.rows = r0 + n
+
+    def select(self, keep: np.ndarray) -> None:
+        """Keep the rows ``keep`` (ascending), renumbered 0..len(keep)-1: what a compaction of the index does to its rows."""
+        keep = np.asarray(keep, np.int64)
+        for c in self.INT_COLS:
+            self._host[c] = np.ascontiguousarray(self._host[c][: self.rows][keep])
+        self._names = np.ascontiguousarray(self._names[: self.rows][keep])
+        if self._node_keys:
+            self._node_keys = [self._node_keys[int(i)] for i in keep]
+        self.rows = int(keep.size)
+        self._dev, self._dev_rows = None, 0          # re-uploaded on the next gather
+        self._dirty.clear()
 
     def set_degrees(self, total_degree: dict[str, int]) -> None:
         """``{centrality key: total_degree}`` as the graph reports it; keys it does not know stay at -1."""

@@ -30,6 +30,10 @@ class HotPathSettings:
     hip_store_dtype: str
     hip_initial_capacity: int
     hip_weights: str | None
+    hip_shards: int
+    hip_shard_backend: str
+    hip_compact_dead_fraction: float
+    hip_compact_min_dead: int
 
 
 def get_settings() -> HotPathSettings:
@@ -46,4 +50,8 @@ def get_settings() -> HotPathSettings:
         hip_store_dtype=os.environ.get("CODERAG_HIP_STORE_DTYPE", "f32").lower(),
         hip_initial_capacity=_int("CODERAG_HIP_INITIAL_CAPACITY", 65536),
         hip_weights=os.environ.get("CODERAG_HIP_WEIGHTS") or None,
+        hip_shards=_int("CODERAG_HIP_SHARDS", 1),                      # row shards per collection (store.py)
+        hip_shard_backend=os.environ.get("CODERAG_HIP_SHARD_BACKEND", "auto").lower(),     # local | dist | auto
+        hip_compact_dead_fraction=float(os.environ.get("CODERAG_HIP_COMPACT_DEAD_FRACTION", "0.25") or 0.25),
+        hip_compact_min_dead=_int("CODERAG_HIP_COMPACT_MIN_DEAD", 1024),
     )

@@ -1,0 +1,242 @@
+"""Row shards of one collection behind ``HipVectorStore`` (BASELINE configs[3] / [4]: "corpus row-sharded across the GPUs").
+
+``north_star`` keeps the reference's ``VectorStore`` surface (``embeddings/client.py:18-228``) and shards the corpus behind it;
+this is the piece between the two.  A ``ShardSet`` looks like one index to ``store._Collection`` -- append, tombstone,
+delete / count / match by filter, search, compact, save / load -- and spreads the rows over ``n`` ``crh_index`` handles:
+
+* ``backend="local"``: all shards live in this process (on one device, or one per listed device).  What a one-GPU box can run;
+  the search is n scans -> ``crh_merge_topk_strided`` on the device.
+* ``backend="dist"``: one process per GPU under ``torch.distributed`` (``nccl`` = RCCL over xGMI); every rank makes the SAME
+  calls (the host tables are replicated, the vectors are not) and owns shard ``rank``.  The search is the path of
+  ``sharded.ShardedIndex``: local scan with ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.
+  Control-plane results (counts, matching rows, compaction maps) travel as small host objects.
+
+Rows are dealt to the shards in blocks of ``block`` rows, round robin, so shards stay balanced under incremental upserts.
+A row's global id is ``shard * STRIDE + local row`` (``STRIDE`` = 2^32, a ``crh_index`` holds at most 2^31 rows): stable under
+appends and capacity growth.  Ties between equal scores go to the lower global id (lower shard first) -- Qdrant leaves tie
+order unspecified.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import ffi
+
+STRIDE = 1 << 32
+
+
+class ShardSet:
+    def __init__(self, nshards: int, make_index: Callable[[int], Any], device: int = 0, backend: str = "local", group=None,
+                 block: int = 4096, merge_fn: Callable | None = None):
+        if nshards < 1:
+            raise ValueError("a collection needs at least one shard")
+        self.ns, self.block, self.device, self._merge_host = int(nshards), int(block), device, merge_fn
+        self.backend, self.group, self.dist, self.rank = backend, group, None, None
+        if backend == "dist":
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("shard backend 'dist' needs an initialised torch.distributed process group (one process per GPU)")
+            if dist.get_world_size(group) != self.ns:
+                raise ValueError(f"{self.ns} shards but a process group of {dist.get_world_size(group)} ranks")
+            self.dist, self.rank = dist, dist.get_rank(group)
+            self.owned = [self.rank]
+        elif backend == "local":
+            self.owned = list(range(self.ns))
+        else:
+            raise ValueError(f"unknown shard backend {backend!r} (use 'local' or 'dist')")
+        self.index = {s: make_index(s) for s in self.owned}
+        self.rows = [0] * self.ns                 # rows appended to every shard so far (replicated bookkeeping: same on every rank)
+        self._next_block = 0
+        first = self.index[self.owned[0]]
+        self.dim, self.dtype = first.dim, first.dtype
+
+    # ------------------------------------------------------------------ plumbing
+    def _everyone(self, mine: Any) -> list:
+        """``mine`` of every rank, in rank order (backend "dist"); a one-element list otherwise."""
+        if self.dist is None:
+            return [mine]
+        out = [None] * self.ns
+        self.dist.all_gather_object(out, mine, group=self.group)
+        return out
+
+    @property
+    def capacity_rows(self) -> int:
+        return sum(ix.capacity_rows for ix in self.index.values())
+
+    def count(self) -> tuple[int, int]:
+        alive = sum(self._everyone(sum(ix.count()[1] for ix in self.index.values())))
+        return sum(self.rows), int(alive)
+
+    # ------------------------------------------------------------------ build
+    def route(self, n: int) -> np.ndarray:
+        """Shard of each of the next ``n`` appended rows: blocks of ``block`` rows, round robin, continuing where the previous
+        append stopped."""
+        if self.ns == 1:
+            return np.zeros((n,), np.int32)
+        blocks = (n + self.block - 1) // self.block
+        sh = (np.arange(blocks, dtype=np.int64) + self._next_block) % self.ns
+        self._next_block = int((self._next_block + blocks) % self.ns)
+        return np.repeat(sh, self.block)[:n].astype(np.int32)
+
+    def append(self, vecs, codes, preprocessed: bool = False, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
+        """Append n rows (numpy [n, dim] or a CUDA tensor; codes numpy [n, cols] or None).  Returns (shard [n], local row [n])."""
+        n = int(vecs.shape[0])
+        shard = self.route(n)
+        local = np.empty((n,), np.int64)
+        on_dev = not isinstance(vecs, np.ndarray)
+        for s in range(self.ns):
+            sel = np.flatnonzero(shard == s) if self.ns > 1 else None
+            m = n if sel is None else int(sel.size)
+            if m == 0:
+                continue
+            first = self.rows[s]
+            if sel is None:
+                local[:] = first + np.arange(n)
+            else:
+                local[sel] = first + np.arange(m)
+            if s in self.index:
+                ix = self.index[s]
+                if first + m > ix.capacity_rows:
+                    ix.reserve(max(first + m, 2 * ix.capacity_rows))
+                if sel is None:
+                    v, c = vecs, codes
+                elif on_dev:
+                    import torch
+                    v = vecs.index_select(0, torch.from_numpy(sel).to(vecs.device))
+                    c = codes[sel] if codes is not None else None
+                else:
+                    v, c = vecs[sel], (codes[sel] if codes is not None else None)
+                if on_dev and c is not None:
+                    import torch
+                    c = torch.from_numpy(np.ascontiguousarray(c)).to(v.device)
+                got = ix.append(v, c, stream=stream, preprocessed=preprocessed) if on_dev else ix.append(v, c, preprocessed=preprocessed)
+                if got != first:
+                    raise RuntimeError(f"shard {s}: append landed at row {got}, the bookkeeping expected {first}")
+            self.rows[s] = first + m
+        return shard, local
+
+    def tombstone(self, shard: np.ndarray, local: np.ndarray) -> None:
+        for s, ix in self.index.items():
+            sel = local[shard == s] if self.ns > 1 else local
+            if len(sel):
+                ix.tombstone(np.asarray(sel, np.int64))
+
+    def tombstone_filter(self, dfilt) -> int:
+        return int(sum(self._everyone(sum(ix.tombstone_filter(dfilt) for ix in self.index.values()))))
+
+    def count_matching(self, dfilt) -> int:
+        return int(sum(self._everyone(sum(ix.count_matching(dfilt) for ix in self.index.values()))))
+
+    def match_rows(self, dfilt, limit: int) -> tuple[np.ndarray, np.ndarray]:
+        """(shard, local row) of up to ``limit`` alive matching rows PER SHARD, ascending inside each shard (a caller that wants
+        the first ``limit`` in insertion order sorts the union by slot and cuts)."""
+        mine = {s: ix.match_rows(dfilt, limit) for s, ix in self.index.items()}
+        allr: dict[int, np.ndarray] = {}
+        for part in self._everyone(mine):
+            allr.update(part)
+        sh = np.concatenate([np.full((len(allr[s]),), s, np.int32) for s in sorted(allr)]) if allr else np.zeros((0,), np.int32)
+        lo = np.concatenate([np.asarray(allr[s], np.int64) for s in sorted(allr)]) if allr else np.zeros((0,), np.int64)
+        return sh, lo
+
+    # ------------------------------------------------------------------ query
+    def search(self, queries: np.ndarray, k: int, dfilt) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Exact top-k over all shards: (scores [nq, k], shard [nq, k], local row [nq, k]); -1 rows are padding."""
+        if self.ns == 1:
+            s, r = self.index[0].search(queries, k, filters=dfilt)
+            return s, np.zeros(r.shape, np.int32), r
+        if self._merge_host is not None:            # injected host-side index + merge (CPU test tier)
+            scores, rows = self._search_host(queries, k, dfilt)
+        else:
+            sd, rd = self.search_device(queries, k, dfilt)
+            scores, rows = sd.cpu().numpy(), rd.cpu().numpy()
+        return scores, np.where(rows >= 0, rows // STRIDE, 0).astype(np.int32), np.where(rows >= 0, rows % STRIDE, -1)
+
+    def _search_host(self, queries, k, dfilt):
+        nq = int(queries.shape[0])
+        mine = {s: ix.search(queries, k, filters=dfilt, row_base=s * STRIDE) for s, ix in self.index.items()}
+        if self.dist is None:
+            parts = mine
+        else:                                        # the same single all-gather of [scores | rows] records as on the device
+            import torch
+            local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, self.ns, nq, k, torch.device("cpu"))
+            ms, mr = mine[self.rank]
+            loc_s.copy_(torch.from_numpy(np.ascontiguousarray(ms)))
+            loc_r.copy_(torch.from_numpy(np.ascontiguousarray(mr)))
+            self.dist.all_gather_into_tensor(gathered.view(-1), local, group=self.group)
+            return self._merge_host(all_s.numpy(), all_r.numpy())
+        ss = np.stack([parts[s][0] for s in range(self.ns)])
+        rr = np.stack([parts[s][1] for s in range(self.ns)])
+        return self._merge_host(ss, rr)
+
+    def search_device(self, queries, k: int, dfilt):
+        """The same on the device, results left there: (scores f32 [nq, k], GLOBAL rows i64 [nq, k]) CUDA tensors -- per-shard
+        ``crh_search`` with ``row_base`` = shard * STRIDE, [one all-gather of the records,] ``crh_merge_topk_strided``."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        ffi.use_device(self.device)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        qd = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(dev)
+        nq = int(qd.shape[0])
+        local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, self.ns, nq, k, dev)
+        if self.dist is None:
+            for s, ix in self.index.items():         # every shard writes its own record of the "gathered" buffer
+                ix.search(qd, k, filters=dfilt, row_base=s * STRIDE, out_scores=all_s[s], out_rows=all_r[s], stream=stream)
+            for ix in self.index.values():
+                ix.search_finish(stream)
+        else:
+            ix = self.index[self.rank]
+            ix.search(qd, k, filters=dfilt, row_base=self.rank * STRIDE, out_scores=loc_s, out_rows=loc_r, stream=stream)
+            ix.search_finish(stream)
+            self.dist.all_gather_into_tensor(gathered.view(-1), local, group=self.group)
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        out_r = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        ffi.merge_topk(all_s, all_r, out_s, out_r, stream)
+        return out_s, out_r
+
+    def complete_columns(self, packed) -> None:
+        """Side columns of a merged candidate table: every rank gathered the rows it owns (zeros elsewhere); ONE all-reduce of
+        the packed buffer completes them (``sharded.ShardedIndex.gather_columns``).  Local shards are summed by the caller."""
+        if self.dist is not None:
+            self.dist.all_reduce(packed, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    # ------------------------------------------------------------------ maintenance
+    def compact(self) -> dict[int, np.ndarray]:
+        """``crh_index_compact`` on every shard; returns {shard: old_to_new local rows} for ALL shards on every rank."""
+        mine = {s: ix.compact() for s, ix in self.index.items()}
+        maps: dict[int, np.ndarray] = {}
+        for part in self._everyone(mine):
+            maps.update(part)
+        for s, o2n in maps.items():
+            self.rows[s] = int((o2n >= 0).sum())
+        return maps
+
+    def stats(self) -> dict:
+        out: dict[str, int] = {}
+        for ix in self.index.values():
+            for k, v in ix.stats().items():
+                out[k] = (max(out.get(k, 0), v) if k in ("max_query_cands", "fallback_used") else out.get(k, 0) + v)
+        return out
+
+    def save(self, directory: str) -> None:
+        for s, ix in self.index.items():
+            ix.save(directory if self.ns == 1 else os.path.join(directory, f"shard{s}"))
+
+    def load(self, directory: str) -> None:
+        for s, ix in self.index.items():
+            ix.load(directory if self.ns == 1 else os.path.join(directory, f"shard{s}"))
+        counts: dict[int, int] = {}
+        for part in self._everyone({s: ix.count()[0] for s, ix in self.index.items()}):
+            counts.update(part)
+        self.rows = [int(counts[s]) for s in range(self.ns)]
+
+    def close(self) -> None:
+        for ix in self.index.values():
+            ix.close()
+
+
+def shard_sizes(rows: Sequence[int]) -> str:
+    return "/".join(str(int(r)) for r in rows)

@@ -27,6 +27,8 @@ import numpy as np
 from . import ffi
 from .errors import VectorStoreError
 from .settings import get_settings
+from .shards import STRIDE as SHARD_STRIDE, ShardSet
+from .tables import DICT_KEYS, IdTable, PayloadTable
 
 logger = logging.getLogger(__name__)
 
@@ -63,76 +65,102 @@ class CollectionInfo:
     config: dict = field(default_factory=dict)
 
 
-def _hashable(v: Any) -> Any:
-    try:
-        hash(v)
-        return v
-    except TypeError:
-        return repr(v)
-
-
 class _Collection:
-    """One collection: a device index + the host-side id / payload tables.
+    """One collection: row shards on the device(s) + the host-side id / payload tables.
 
     What lives where: vectors, validity bits and the dictionary CODES of the filterable payload keys are on the device
-    (columnar int32, one column per key); the host keeps, per row, only the id string and the payload dictionary a hit has
-    to carry back, plus one value<->code dictionary per key.  Filters, deletes and the update check are resolved on the
-    device from the code columns (``crh_index_match_rows`` / ``crh_index_tombstone_filter``): no per-row Python sets, no
-    host copy of the validity bits.  Rows are never reused, so a deleted row's id / payload entries are simply left behind
-    (a stale ``row_of_id`` entry only ever leads to tombstoning a dead row again, which the device ignores) and are dropped
-    when the collection is saved."""
+    (columnar int32, one column per key; ``shards.ShardSet`` spreads the rows over one or more ``crh_index`` handles).  The
+    host keeps what a hit has to carry back -- ids and payloads, by SLOT (insertion order), columnar (``tables.IdTable`` /
+    ``tables.PayloadTable``: no Python object per row) -- and the map slot <-> (shard, local row).  Filters, deletes and the
+    update check are resolved on the device from the code columns.  A deleted row keeps its slot until ``compact()``
+    (``crh_index_compact``) moves the survivors together on the device and in the tables; the store compacts by itself once
+    the dead rows pass a fraction of the collection (the reference deletes and re-inserts every chunk of a file on every
+    indexing run, embeddings/indexer.py:61-64)."""
 
-    def __init__(self, name: str, dim: int, dtype: int, capacity: int, device: int):
+    def __init__(self, name: str, dim: int, dtype: int, capacity: int, device: int, nshards: int = 1, backend: str = "local",
+                 group=None, merge_fn=None, compact_dead_fraction: float = 0.25, compact_min_dead: int = 1024):
         self.name = name
         self.keys = FILTER_KEYS.get(name, ())
-        self.index = ffi.Index(dim, dtype, capacity_rows=capacity, n_code_cols=len(self.keys), device=device)
-        self.ids: list[str | None] = []
-        self.payloads: list[dict | None] = []
-        self.row_of_id: dict[str, int] = {}
-        self.codebooks: list[dict[Any, int]] = [dict() for _ in self.keys]   # value -> code (>= 1; 0 = missing/None)
-        self._side = None          # ranking.device.SideColumns of the rows appended so far (built on first use)
+        ncols = len(self.keys)
+        self.shards = ShardSet(nshards, lambda s: ffi.Index(dim, dtype, capacity_rows=capacity, n_code_cols=ncols, device=device),
+                               device=device, backend=backend, group=group, merge_fn=merge_fn)
+        self.ids = IdTable()
+        self.payloads = PayloadTable(tuple(DICT_KEYS) + tuple(self.keys))
+        # slot <-> row.  With ONE shard a slot IS its row (rows are appended and compacted in slot order): no map is kept.
+        self.row_shard = np.zeros((0,), np.int32)
+        self.row_local = np.zeros((0,), np.int64)
+        self.slot_of: list[np.ndarray] = [np.zeros((0,), np.int64) for _ in range(self.shards.ns)]
+        self._side: dict[int, Any] = {}      # shard -> ranking.device.SideColumns of its rows (built on first use)
+        self._side_books = None
         self._degrees: dict[str, int] | None = None
         self._device = device
+        self.compact_dead_fraction, self.compact_min_dead = compact_dead_fraction, compact_min_dead
+        self.compactions = 0
 
-    def side_columns(self):
-        """Per-row side data for the device re-rank (ranking/device.py), extended lazily as rows are appended."""
+    @property
+    def index(self):
+        """The one ``crh_index`` of an unsharded collection (tools and tests look at it)."""
+        if self.shards.ns != 1:
+            raise AttributeError("a sharded collection has no single index (use .shards)")
+        return self.shards.index[0]
+
+    # -- slots and rows
+    def rows_of(self, slots: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        slots = np.asarray(slots, np.int64)
+        if self.shards.ns == 1:
+            return np.zeros(slots.shape, np.int32), slots
+        return self.row_shard[slots], self.row_local[slots]
+
+    def slots_of(self, shard: np.ndarray, local: np.ndarray) -> np.ndarray:
+        """Slots of rows (shard, local); -1 stays -1."""
+        local = np.asarray(local, np.int64)
+        if self.shards.ns == 1:
+            return local
+        out = np.full(local.shape, -1, np.int64)
+        for s in range(self.shards.ns):
+            m = (np.asarray(shard) == s) & (local >= 0)
+            if m.any():
+                out[m] = self.slot_of[s][local[m]]
+        return out
+
+    def side_columns(self) -> dict[int, Any]:
+        """Per-shard side data for the device re-rank (ranking/device.py), extended lazily as rows are appended; the
+        dictionaries behind the file / merge-key / node codes are shared by the shards (candidates of different shards are
+        compared by code)."""
         from .ranking.device import SideColumns
-        if self._side is None:
-            self._side = SideColumns(self._device)
-        if self._side.rows < len(self.payloads):
-            self._side.append(self.payloads[self._side.rows:])
-            if self._degrees is not None:
-                self._side.set_degrees(self._degrees)
+        if self._side_books is None:
+            self._side_books = {"file": {}, "key": {}, "node": {}}
+        for s in self.shards.owned:
+            side = self._side.get(s)
+            if side is None:
+                side = self._side[s] = SideColumns(self._device, books=self._side_books)
+            have, want = side.rows, self.shards.rows[s]
+            if have < want:
+                slots = np.arange(have, want) if self.shards.ns == 1 else self.slot_of[s][have:want]
+                side.append([self.payloads.get(int(t)) for t in slots])
+                if self._degrees is not None:
+                    side.set_degrees(self._degrees)
         return self._side
+
+    def gather_side(self, rows_dev):
+        """Side columns of a candidate table of GLOBAL rows (CUDA int64 [nq, k]), complete over all shards."""
+        sides = self.side_columns()
+        total = None
+        for s in self.shards.owned:
+            cols = sides[s].gather(rows_dev, row_base=s * SHARD_STRIDE)
+            if total is None:
+                total = cols
+            else:
+                total.packed += cols.packed
+        self.shards.complete_columns(total.packed)
+        return total
 
     def set_degrees(self, total_degree: dict[str, int]) -> None:
         self._degrees = dict(total_degree)
-        if self._side is not None:
-            self._side.set_degrees(self._degrees)
+        for side in self._side.values():
+            side.set_degrees(self._degrees)
 
-    # -- payload coding
-    def _encode_columns(self, payloads: list[dict]) -> np.ndarray:
-        """[n, n_keys] int32 codes, one key (= one device column) at a time."""
-        codes = np.zeros((len(payloads), len(self.keys)), dtype=np.int32)
-        for c, key in enumerate(self.keys):
-            book = self.codebooks[c]
-            col = []
-            for p in payloads:
-                v = p.get(key)
-                if v is None:
-                    col.append(0)
-                    continue
-                try:
-                    code = book.get(v)
-                except TypeError:           # an unhashable value (list / dict payload field)
-                    v = repr(v)
-                    code = book.get(v)
-                if code is None:
-                    code = book[v] = len(book) + 1
-                col.append(code)
-            codes[:, c] = col
-        return codes
-
+    # -- filters
     def device_filters(self, filters: dict[str, Any] | None) -> list[tuple[int, int]] | None:
         """dict -> [(column, code)]; None when some value was never stored (nothing can match)."""
         out = []
@@ -140,25 +168,26 @@ class _Collection:
             if key not in self.keys:
                 raise ValueError(f"collection {self.name!r} cannot filter on payload key {key!r} "
                                  f"(filterable: {', '.join(self.keys)})")
-            c = self.keys.index(key)
-            code = 0 if value is None else self.codebooks[c].get(_hashable(value))
+            code = self.payloads.cols[key].code_of(value)
             if code is None:
                 return None
-            out.append((c, code))
+            out.append((self.keys.index(key), code))
         return out
 
-    def matching_rows(self, filters: dict[str, Any] | None, limit: int | None = None) -> np.ndarray:
-        """Alive rows matching every equality, ascending -- resolved on the device from the code columns."""
+    def matching_slots(self, filters: dict[str, Any] | None, limit: int | None = None) -> np.ndarray:
+        """Alive slots matching every equality, in insertion order -- resolved on the device from the code columns."""
         dfilt = self.device_filters(filters)
         if dfilt is None:
             return np.zeros((0,), np.int64)
-        return self.index.match_rows(dfilt, self.index.count()[0] if limit is None else limit)
+        sh, lo = self.shards.match_rows(dfilt, sum(self.shards.rows) if limit is None else limit)
+        slots = np.sort(self.slots_of(sh, lo))
+        return slots if limit is None else slots[:limit]
 
     # -- mutation
-    def remove_rows(self, rows) -> None:
-        rows = np.asarray(rows, dtype=np.int64)
-        if rows.size:
-            self.index.tombstone(rows)
+    def remove_slots(self, slots) -> None:
+        slots = np.asarray(slots, dtype=np.int64)
+        if slots.size:
+            self.shards.tombstone(*self.rows_of(slots))
 
     def delete(self, filters: dict[str, Any]) -> int:
         """client.py:159-169: every point matching the AND of equalities.  An empty filter matches every point, as
@@ -167,10 +196,13 @@ class _Collection:
         if dfilt is None:
             return 0
         if not dfilt:
-            rows = self.index.match_rows(None, self.index.count()[0])
-            self.remove_rows(rows)
-            return int(rows.size)
-        return self.index.tombstone_filter(dfilt)
+            slots = self.matching_slots(None)
+            self.remove_slots(slots)
+            n = int(slots.size)
+        else:
+            n = self.shards.tombstone_filter(dfilt)
+        self.maybe_compact()
+        return n
 
     def upsert(self, ids, vectors, payloads, preprocessed: bool = False) -> None:
         """``vectors``: list of float lists (what the reference passes), a float32 ndarray [n, dim], or a CUDA tensor [n, dim]
@@ -182,8 +214,8 @@ class _Collection:
         vecs = vectors if on_dev else np.asarray(vectors, dtype=np.float32)
         if vecs.ndim != 2 or int(vecs.shape[0]) != n or len(payloads) != n:
             raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {tuple(vecs.shape)}, {len(payloads)})")
-        if int(vecs.shape[1]) != self.index.dim:
-            raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.index.dim}")
+        if int(vecs.shape[1]) != self.shards.dim:
+            raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.shards.dim}")
         ids = [str(i) for i in ids]
         last = dict(zip(ids, range(n)))                       # a repeated id inside one call: last one wins
         if len(last) != n:
@@ -191,47 +223,106 @@ class _Collection:
             ids, payloads = [ids[i] for i in keep], [payloads[i] for i in keep]
             vecs = vecs[keep] if not on_dev else vecs[ffi_index_tensor(vecs, keep)]
             n = len(keep)
-        known = self.row_of_id
-        stale = [known[pid] for pid in ids if pid in known]
-        codes = self._encode_columns(payloads)
-        rows_now, _ = self.index.count()
-        need = rows_now + n
-        if need > self.index.capacity_rows:
-            self.index.reserve(max(need, 2 * self.index.capacity_rows))
-        if on_dev:
-            import torch
-            vecs = vecs.contiguous() if vecs.dtype == torch.float32 else vecs.float().contiguous()
-            cdev = torch.from_numpy(codes).to(vecs.device) if self.keys else None
-            first = self.index.append(vecs, cdev, stream=ffi.current_stream(vecs.device), preprocessed=preprocessed)
-            torch.cuda.current_stream(vecs.device).synchronize()      # the caller may free / reuse its tensor right away
-        else:
-            first = self.index.append(vecs, codes if self.keys else None, preprocessed=preprocessed)
-        if stale:
-            self.remove_rows(stale)
-        self.ids.extend(ids)
-        self.payloads.extend([dict(p) for p in payloads])
-        known.update(zip(ids, range(first, first + n)))
+        n0 = self.payloads.n
+        self.payloads.extend(payloads)
+        try:
+            codes = self.payloads.device_codes(self.keys, n0, n0 + n) if self.keys else None
+            if on_dev:
+                import torch
+                vecs = vecs.contiguous() if vecs.dtype == torch.float32 else vecs.float().contiguous()
+                shard, local = self.shards.append(vecs, codes, preprocessed, stream=ffi.current_stream(vecs.device))
+                torch.cuda.current_stream(vecs.device).synchronize()      # the caller may free / reuse its tensor right away
+            else:
+                shard, local = self.shards.append(vecs, codes, preprocessed)
+        except Exception:
+            self.payloads.truncate(n0)                        # nothing was stored: the tables go back to where they were
+            raise
+        replaced = self.ids.extend(ids)                       # slots these ids occupied before (-1: new)
+        if self.shards.ns > 1:
+            self.row_shard = np.concatenate([self.row_shard, shard])
+            self.row_local = np.concatenate([self.row_local, local])
+            for s in range(self.shards.ns):
+                m = shard == s
+                if m.any():
+                    self.slot_of[s] = np.concatenate([self.slot_of[s], n0 + np.flatnonzero(m)])
+        stale = replaced[replaced >= 0]
+        if stale.size:
+            self.remove_slots(stale)                          # (a slot that is already dead is tombstoned again: the device ignores it)
+            self.maybe_compact()
 
-    def hit(self, row: int, score: float) -> dict[str, Any]:
-        return {"id": self.ids[row], "score": score, "payload": dict(self.payloads[row] or {})}
+    def hit(self, slot: int, score: float) -> dict[str, Any]:
+        return {"id": self.ids.get(slot), "score": score, "payload": self.payloads.get(slot)}
+
+    def search(self, queries: np.ndarray, limit: int, dfilt) -> tuple[np.ndarray, np.ndarray]:
+        """(scores [nq, limit], slots [nq, limit]); -1 slots are padding."""
+        scores, shard, local = self.shards.search(queries, limit, dfilt)
+        return scores, self.slots_of(shard, local)
+
+    # -- compaction
+    def maybe_compact(self) -> bool:
+        rows, alive = self.shards.count()
+        dead = rows - alive
+        if self.compact_dead_fraction > 0 and dead >= self.compact_min_dead and dead >= self.compact_dead_fraction * rows:
+            self.compact()
+            return True
+        return False
+
+    def compact(self) -> int:
+        """Reclaim the rows of deleted points on the device (``crh_index_compact``) and drop their ids / payloads from the host
+        tables; returns the number of rows reclaimed.  Slots and rows are renumbered; ids, payloads, filters and search
+        results are unchanged."""
+        before = self.payloads.n
+        maps = self.shards.compact()
+        if self.shards.ns == 1:
+            o2n = maps[0]
+            keep = np.flatnonzero(o2n >= 0)
+        else:
+            new_local = np.full((before,), -1, np.int64)
+            for s, o2n in maps.items():
+                m = self.row_shard == s
+                new_local[m] = o2n[self.row_local[m]]
+            keep = np.flatnonzero(new_local >= 0)
+            self.row_shard, self.row_local = self.row_shard[keep], new_local[keep]
+            for s in range(self.shards.ns):
+                m = np.flatnonzero(self.row_shard == s)
+                so = np.empty((m.size,), np.int64)
+                so[self.row_local[m]] = m
+                self.slot_of[s] = so
+        if keep.size != before:
+            self.ids.compact(keep)
+            self.payloads.compact(keep)
+            for s, side in self._side.items():
+                side.select(np.flatnonzero(maps[s][: side.rows] >= 0))
+            self.compactions += 1
+        return int(before - keep.size)
 
     # -- persistence (SURVEY.md section 8f, row 2)
     def save(self, directory: str) -> None:
-        """``directory``: the index image (``ffi.Index.save``: raw, mmap-able, verbatim) + ``ids.jsonl`` / ``payloads.jsonl``
-        (one JSON value per row, ``null`` for a deleted row) + ``collection.json`` (keys, code dictionaries, graph degrees)."""
+        """``directory``: the index image of every shard (``ffi.Index.save``: raw, mmap-able, verbatim) + the id and payload
+        tables as raw arrays (``tables``) + ``collection.json`` (keys, shard layout, graph degrees).  Written next to the
+        target and renamed over it, so a crash mid-save leaves the previous snapshot intact."""
         import json
-        self.index.save(directory)
-        words = self.index.alive_words()
-        alive = np.unpackbits(words.view(np.uint8), bitorder="little")[: len(self.ids)].astype(bool) if len(self.ids) else np.zeros(0, bool)
-        dumps = json.dumps
-        with open(os.path.join(directory, "ids.jsonl"), "w") as fi, open(os.path.join(directory, "payloads.jsonl"), "w") as fp:
-            for r, (pid, payload) in enumerate(zip(self.ids, self.payloads)):
-                ok = alive[r]
-                fi.write((dumps(pid) if ok else "null") + "\n")
-                fp.write((dumps(payload) if ok else "null") + "\n")
-        books = [[v for v, _ in sorted(book.items(), key=lambda kv: kv[1])] for book in self.codebooks]
-        with open(os.path.join(directory, "collection.json"), "w") as f:
-            json.dump({"name": self.name, "keys": list(self.keys), "codebooks": books, "degrees": self._degrees}, f, default=repr)
+        import shutil
+        tmp = directory.rstrip("/") + ".tmp"
+        primary = self.shards.rank in (None, 0)
+        if primary:
+            shutil.rmtree(tmp, ignore_errors=True)
+            os.makedirs(tmp, exist_ok=True)
+        self.shards._everyone(None)                               # (every rank sees the directory before writing into it)
+        self.shards.save(tmp)
+        if primary:
+            self.ids.save(tmp)
+            self.payloads.save(tmp)
+            self.row_shard.tofile(os.path.join(tmp, "rows.shard.i32"))
+            self.row_local.tofile(os.path.join(tmp, "rows.local.i64"))
+            with open(os.path.join(tmp, "collection.json"), "w") as f:
+                json.dump({"name": self.name, "keys": list(self.keys), "format": 3, "slots": self.payloads.n, "shards": self.shards.ns,
+                           "shard_rows": list(self.shards.rows), "degrees": self._degrees}, f, default=repr)
+        self.shards._everyone(None)
+        if primary:
+            shutil.rmtree(directory, ignore_errors=True)
+            os.replace(tmp, directory)
+        self.shards._everyone(None)
 
     def load(self, directory: str) -> None:
         import json
@@ -239,21 +330,28 @@ class _Collection:
             meta = json.load(f)
         if list(meta["keys"]) != list(self.keys):
             raise ValueError(f"snapshot of {self.name} codes the payload keys {meta['keys']}, this store {list(self.keys)}")
-        self.index.load(directory)
-        self.codebooks = [{_hashable(v): i + 1 for i, v in enumerate(book)} for book in meta["codebooks"]]
-        with open(os.path.join(directory, "ids.jsonl")) as f:
-            self.ids = [json.loads(line) for line in f]
-        with open(os.path.join(directory, "payloads.jsonl")) as f:
-            self.payloads = [json.loads(line) for line in f]
-        rows, _ = self.index.count()
-        if len(self.ids) != rows or len(self.payloads) != rows:
-            raise ValueError(f"snapshot of {self.name}: {rows} rows in the index, {len(self.ids)} ids, {len(self.payloads)} payloads")
-        self.row_of_id = {pid: r for r, pid in enumerate(self.ids) if pid is not None}
-        self._side = None
+        if int(meta.get("shards", 1)) != self.shards.ns:
+            raise ValueError(f"snapshot of {self.name} has {meta.get('shards', 1)} shards, this store {self.shards.ns}")
+        self.shards.load(directory)
+        n = int(meta["slots"])
+        self.ids.load(directory, n)
+        self.payloads.load(directory)
+        self.row_shard = np.fromfile(os.path.join(directory, "rows.shard.i32"), np.int32)
+        self.row_local = np.fromfile(os.path.join(directory, "rows.local.i64"), np.int64)
+        if self.payloads.n != n or sum(self.shards.rows) != n or list(self.shards.rows) != [int(v) for v in meta["shard_rows"]]:
+            raise ValueError(f"snapshot of {self.name}: {self.shards.rows} rows in the shards, {n} ids, {self.payloads.n} payloads")
+        self.slot_of = [np.zeros((0,), np.int64) for _ in range(self.shards.ns)]
+        if self.shards.ns > 1:
+            for s in range(self.shards.ns):
+                m = np.flatnonzero(self.row_shard == s)
+                so = np.empty((m.size,), np.int64)
+                so[self.row_local[m]] = m
+                self.slot_of[s] = so
+        self._side = {}
         self._degrees = meta.get("degrees")
 
     def close(self) -> None:
-        self.index.close()
+        self.shards.close()
 
 
 def ffi_index_tensor(vecs, keep):
@@ -298,11 +396,12 @@ class _RawClient:
             if key not in col.keys:
                 return None
             c = col.keys.index(key)
+            book = col.payloads.cols[key]
             if kind == "value":
-                code = 0 if value is None else col.codebooks[c].get(_hashable(value))
+                code = book.code_of(value)
                 opts = [] if code is None else [(c, code)]
             else:
-                opts = [(c, code) for v, code in col.codebooks[c].items() if isinstance(v, str) and str(value) in v]
+                opts = [(c, i + 1) for i, v in enumerate(book.values) if isinstance(v, str) and str(value) in v]
             choices.append(opts)
         plans: list[list[tuple[int, int]]] = [[]]
         for opts in choices:
@@ -312,16 +411,16 @@ class _RawClient:
         return plans
 
     def _host_select(self, col: _Collection, conds) -> np.ndarray:
-        rows = []
-        for r in col.index.match_rows(None, col.index.count()[0]):
-            p = col.payloads[int(r)] or {}
+        """Slots whose payload meets conditions on keys the device does not code: a walk over the alive slots' columns."""
+        slots = []
+        for t in col.matching_slots(None):
             ok = True
             for key, kind, value in conds:
-                have = p.get(key)
+                have = col.payloads.value(int(t), key)
                 ok = ok and ((isinstance(have, str) and str(value) in have) if kind == "text" else have == value)
             if ok:
-                rows.append(int(r))
-        return np.asarray(rows, dtype=np.int64)
+                slots.append(int(t))
+        return np.asarray(slots, dtype=np.int64)
 
     async def count(self, collection_name: str, count_filter=None, exact: bool = True):
         def work():
@@ -330,7 +429,7 @@ class _RawClient:
             plans = self._device_plans(col, conds)
             if plans is None:
                 return int(self._host_select(col, conds).size)
-            return sum(col.index.count_matching(p) for p in plans)      # (plans differ in at least one code: disjoint)
+            return sum(col.shards.count_matching(p) for p in plans)      # (plans differ in at least one code: disjoint)
         n = await self._store._run(work)
         return type("CountResult", (), {"count": n})()
 
@@ -342,13 +441,14 @@ class _RawClient:
             conds = self._conditions(flt)
             plans = self._device_plans(col, conds)
             if plans is None:
-                col.remove_rows(self._host_select(col, conds))
-                return
-            for p in plans:
-                if p:
-                    col.index.tombstone_filter(p)
-                else:                                   # no condition at all: every point
-                    col.remove_rows(col.index.match_rows(None, col.index.count()[0]))
+                col.remove_slots(self._host_select(col, conds))
+            else:
+                for p in plans:
+                    if p:
+                        col.shards.tombstone_filter(p)
+                    else:                               # no condition at all: every point
+                        col.remove_slots(col.matching_slots(None))
+            col.maybe_compact()
         await self._store._run(work)
 
 
@@ -358,7 +458,9 @@ class HipVectorStore:
 
     def __init__(self, host: str | None = None, port: int | None = None, grpc_port: int | None = None, *,
                  device: int | None = None, dim: int | None = None, dtype: str | None = None,
-                 initial_capacity: int | None = None, search_window_ms: float | None = None):
+                 initial_capacity: int | None = None, search_window_ms: float | None = None, shards: int | None = None,
+                 shard_backend: str | None = None, process_group=None, compact_dead_fraction: float | None = None,
+                 compact_min_dead: int | None = None, _merge_fn=None):
         s = get_settings()
         self._host, self._port, self._grpc_port = host, port, grpc_port
         self._device = s.hip_device if device is None else device
@@ -372,6 +474,26 @@ class HipVectorStore:
             raise VectorStoreError(f"Unknown store dtype {name!r} (use 'f32' or 'bf16')")
         self._dtype = _DTYPES[name]
         self._capacity = initial_capacity or s.hip_initial_capacity
+        # Row shards (BASELINE configs[3]: the corpus row-sharded over the GPUs): `shards` handles per collection.  Backend
+        # "local": all of them in this process (what a one-GPU box can run); "dist": one process per GPU under
+        # torch.distributed -- every rank constructs the same store and makes the same calls, the vectors of a collection are
+        # spread over the ranks and every search ends with ONE all-gather + merge (shards.ShardSet).  Default: "dist" when a
+        # process group with as many ranks as shards is up, "local" otherwise.
+        self._shards = int(shards if shards is not None else s.hip_shards)
+        if shard_backend is None:
+            shard_backend = s.hip_shard_backend
+        if shard_backend == "auto":
+            shard_backend = "local"
+            if self._shards > 1:
+                try:
+                    import torch.distributed as dist
+                    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) == self._shards:
+                        shard_backend = "dist"
+                except ImportError:
+                    pass
+        self._shard_backend, self._group, self._merge_fn = shard_backend, process_group, _merge_fn
+        self._compact = (s.hip_compact_dead_fraction if compact_dead_fraction is None else compact_dead_fraction,
+                         s.hip_compact_min_dead if compact_min_dead is None else compact_min_dead)
         self._collections: dict[str, _Collection] = {}
         self._client: _RawClient | None = None
         self._executor: ThreadPoolExecutor | None = None
@@ -461,7 +583,10 @@ class HipVectorStore:
             def work():
                 for name in (CollectionName.CODE_CHUNKS.value, CollectionName.SUMMARIES.value):
                     if name not in self._collections:
-                        self._collections[name] = _Collection(name, self._dimensions, self._dtype, self._capacity, self._device)
+                        self._collections[name] = _Collection(name, self._dimensions, self._dtype, self._capacity, self._device,
+                                                              nshards=self._shards, backend=self._shard_backend, group=self._group,
+                                                              merge_fn=self._merge_fn, compact_dead_fraction=self._compact[0],
+                                                              compact_min_dead=self._compact[1])
                         logger.info(f"Created collection: {name}")
             await self._run(work)
         except Exception as e:
@@ -481,11 +606,13 @@ class HipVectorStore:
         try:
             def work():
                 col = self._col(collection)
-                rows, alive = col.index.count()
+                rows, alive = col.shards.count()
                 return CollectionInfo(name=col.name, points_count=alive, vectors_count=alive, indexed_vectors_count=alive,
-                                      config={"size": col.index.dim, "distance": "Cosine", "rows_appended": rows,
-                                              "capacity_rows": col.index.capacity_rows,
-                                              "dtype": "bf16" if col.index.dtype == ffi.DTYPE_BF16 else "f32"})
+                                      config={"size": col.shards.dim, "distance": "Cosine", "rows_appended": rows,
+                                              "capacity_rows": col.shards.capacity_rows, "shards": col.shards.ns,
+                                              "shard_rows": list(col.shards.rows), "shard_backend": col.shards.backend,
+                                              "compactions": col.compactions,
+                                              "dtype": "bf16" if col.shards.dtype == ffi.DTYPE_BF16 else "f32"})
             return await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to get collection info for {collection}", cause=e)
@@ -506,8 +633,8 @@ class HipVectorStore:
         nq = queries.shape[0]
         if dfilt is None or limit <= 0:
             return col, np.full((nq, max(limit, 0)), -np.inf, np.float32), np.full((nq, max(limit, 0)), -1, np.int64)
-        scores, rows = col.index.search(queries, limit, filters=dfilt)
-        return col, scores, rows
+        scores, slots = col.search(queries, limit, dfilt)
+        return col, scores, slots
 
     async def search(self, collection: str, query_vector: list[float] | None, limit: int = 10,
                      filters: dict[str, Any] | None = None) -> list[dict[str, Any]]:
@@ -517,10 +644,10 @@ class HipVectorStore:
             if query_vector is None:
                 def fetch():
                     col = self._col(collection)
-                    return [col.hit(int(r), 0.0) for r in col.matching_rows(filters, limit=limit)]
+                    return [col.hit(int(t), 0.0) for t in col.matching_slots(filters, limit=limit)]
                 results = await self._run(fetch)
-            elif len(query_vector) != self._col(collection).index.dim:   # (must not fail the pass it would have joined)
-                raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).index.dim}")
+            elif len(query_vector) != self._col(collection).shards.dim:   # (must not fail the pass it would have joined)
+                raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).shards.dim}")
             elif limit > ffi.MAX_K:                                      # (likewise: only THIS caller is refused)
                 raise ValueError(f"limit {limit} exceeds the index's maximum k of {ffi.MAX_K}")
             elif self._search_coalesce:
@@ -541,7 +668,7 @@ class HipVectorStore:
         its own prefix (an exact top-k list is a prefix of every longer one)."""
         loop = asyncio.get_running_loop()
         name = collection.value if isinstance(collection, CollectionName) else collection
-        key = (name, tuple(sorted((k, _hashable(v)) for k, v in (filters or {}).items())))
+        key = (name, tuple(sorted((k, repr(v)) for k, v in (filters or {}).items())))
         vec = np.asarray(query_vector, dtype=np.float32).reshape(-1)
         fut: asyncio.Future = loop.create_future()
         self._search_pending.setdefault(key, []).append((vec, int(limit), fut))
@@ -590,8 +717,8 @@ class HipVectorStore:
     async def search_rerank_batch(self, collection: str, query_vectors, plans, reranker, limit: int = 20,
                                   filters: dict[str, Any] | None = None):
         """One corpus scan for all queries, then the hybrid re-rank of every candidate list on the device
-        (``ranking.device.DeviceReranker``): returns ``(collection, output, rows, scores)`` -- the :class:`RerankOutput` and the
-        host copies of the [nq, limit] candidate rows / scores it indexes.  Payloads are read only for the survivors (see
+        (``ranking.device.DeviceReranker``): returns ``(collection, output, slots, scores)`` -- the :class:`RerankOutput` and the
+        host copies of the [nq, limit] candidate slots (``collection.hit(slot, score)``) / scores it indexes.  Payloads are read only for the survivors (see
         ``engine_helpers.search_and_rank_batch_device``)."""
         import torch
         try:
@@ -601,15 +728,15 @@ class HipVectorStore:
                 q = np.ascontiguousarray(np.asarray(query_vectors, dtype=np.float32))
                 nq = q.shape[0]
                 dev = torch.device("cuda", self._device)
-                s = torch.full((nq, limit), float("-inf"), dtype=torch.float32, device=dev)
-                r = torch.full((nq, limit), -1, dtype=torch.int64, device=dev)
                 if dfilt is not None and limit > 0 and nq > 0:
-                    qd = torch.from_numpy(q).to(dev)
-                    col.index.search(qd, limit, filters=dfilt, out_scores=s, out_rows=r,
-                                     stream=torch.cuda.current_stream(dev).cuda_stream)
-                    col.index.search_finish(torch.cuda.current_stream(dev).cuda_stream)
-                out = reranker.rank(s, r, col.side_columns().gather(r), plans)
-                return col, out, r.cpu().numpy(), s.cpu().numpy()
+                    s, r = col.shards.search_device(torch.from_numpy(q).to(dev), limit, dfilt)       # r: GLOBAL rows
+                else:
+                    s = torch.full((nq, limit), float("-inf"), dtype=torch.float32, device=dev)
+                    r = torch.full((nq, limit), -1, dtype=torch.int64, device=dev)
+                out = reranker.rank(s, r, col.gather_side(r), plans)
+                rows = r.cpu().numpy()
+                slots = col.slots_of(np.where(rows >= 0, rows // SHARD_STRIDE, 0), np.where(rows >= 0, rows % SHARD_STRIDE, -1))
+                return col, out, slots, s.cpu().numpy()
             return await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)
@@ -627,20 +754,30 @@ class HipVectorStore:
         try:
             def work():
                 col = self._col(collection)
-                rows = col.matching_rows({"file_path": file_path}, limit=1)
-                if not len(rows):
+                slots = col.matching_slots({"file_path": file_path}, limit=1)
+                if not len(slots):
                     return True
-                return (col.payloads[int(rows[0])] or {}).get("content_hash") != content_hash
+                return col.payloads.value(int(slots[0]), "content_hash") != content_hash
             return bool(await self._run(work))
         except Exception as e:
             logger.warning(f"Error checking file update status: {e}")
             return True
 
+    async def compact(self, collection: str | None = None) -> int:
+        """Reclaim the rows of deleted points (``crh_index_compact`` + the host tables): what Qdrant's optimizer does in the
+        background.  The store also does it by itself once dead rows exceed ``compact_dead_fraction`` of a collection
+        (``CODERAG_HIP_COMPACT_DEAD_FRACTION``, 0 = never).  Returns the number of rows reclaimed."""
+        try:
+            names = [collection.value if isinstance(collection, CollectionName) else collection] if collection else list(self._collections)
+            return int(await self._run(lambda: sum(self._col(n).compact() for n in names)))
+        except Exception as e:
+            raise VectorStoreError("Failed to compact", cause=e)
+
     # ------------------------------------------------------------------ persistence (SURVEY.md section 8f, row 2)
     async def save(self, directory: str) -> None:
         """Write every collection to ``directory/<name>/``: the index image verbatim (raw ``tiles.bin`` the scan's layout,
-        mmap-able; ``alive.u32``; columnar ``codes.i32``; ``master.f32`` for the f32 store) + ``ids.jsonl`` /
-        ``payloads.jsonl`` / ``collection.json``.  No pickle anywhere.  Stands in for the Qdrant volume the reference relies on
+        mmap-able; ``alive.u32``; columnar ``codes.i32``; ``master.f32`` for the f32 store; one sub-directory per shard) + the id
+        and payload tables as raw arrays + ``collection.json``.  No pickle, no per-row JSON.  Stands in for the Qdrant volume the reference relies on
         for restarts (docker-compose.yml:42-43): an indexed project can be reloaded without re-embedding."""
         try:
             def work():

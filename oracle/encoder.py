@@ -99,20 +99,25 @@ def _ln(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.
 
 
 def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray, return_tokens: bool = False,
-            dtype: torch.dtype = torch.float32, bf16_storage: bool = False):
+            dtype: torch.dtype = torch.float32, bf16_storage: bool = False, device: str = "cpu"):
     """ids: int [B, L], right- or arbitrarily padded with cfg.pad_token_id.  Returns sentence embeddings [B, H]
     (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155.
 
     ``bf16_storage=True`` keeps the arithmetic in f32 but rounds to bf16 exactly where the HIP path STORES bf16
     (matrix weights and embedding tables, every activation written between kernels, and the softmax probabilities
     fed to the P.V product): the model of "the same computation at the kernels' storage precision" that the GPU
-    parity test compares against.  Biases and LayerNorm parameters stay f32 there, as in the kernels."""
+    parity test compares against.  Biases and LayerNorm parameters stay f32 there, as in the kernels.
+
+    ``device``: where torch evaluates these same fp32 expressions.  "cpu" is the oracle proper (and the timed CPU baseline);
+    "cuda" runs the identical plain-torch fp32 graph on the GPU (rocBLAS fp32 GEMMs, no bf16, none of this repo's kernels) so
+    that end-to-end parity legs can afford thousands of chunks -- tests/test_c2_gpu.py pins it against the CPU evaluation
+    (<= 2e-5 relative), and ``weights`` may then be a dict of tensors already on that device (see :func:`to_device`)."""
     def rb(t):
         return t.to(torch.bfloat16).to(dtype) if bf16_storage else t
-    W = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in weights.items()}
+    W = to_device(weights, device, dtype)
     if bf16_storage:
         W = {k: (rb(v) if (v.ndim == 2) else v) for k, v in W.items()}
-    ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64))
+    ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(device)
     B, L = ids_t.shape
     H, nh = cfg.hidden_size, cfg.num_heads
     dh = H // nh
@@ -146,8 +151,18 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
                        cfg.layer_norm_eps))
         m = mask.to(dtype)
         sent = (x * m[..., None]).sum(1) / m.sum(-1)[..., None]
-    sent, x = sent.float(), x.float()
+    sent, x = sent.float().cpu(), x.float().cpu()
     return (sent.numpy(), x.numpy()) if return_tokens else sent.numpy()
+
+
+def to_device(weights: dict, device: str = "cpu", dtype: torch.dtype = torch.float32) -> dict:
+    """numpy (or tensor) weights -> tensors of ``dtype`` on ``device``; tensors already there pass through (so a caller
+    that evaluates many batches converts once)."""
+    out = {}
+    for k, v in weights.items():
+        t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
+        out[k] = t.to(device=device, dtype=dtype)
+    return out
 
 
 def synthetic_ids(cfg: EncoderConfig, lengths, seed: int, enc_only_id: int = 5, pad_to: int | None = None) -> np.ndarray:

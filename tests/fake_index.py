@@ -73,6 +73,16 @@ class FakeIndex:
         bits[: len(self.alive)] = self.alive
         return np.packbits(bits, bitorder="little").view(np.uint32).copy()
 
+    def compact(self):
+        o2n = np.full(len(self.alive), -1, np.int64)
+        keep = np.flatnonzero(self.alive)
+        o2n[keep] = np.arange(len(keep))
+        self.x, self.codes, self.alive = self.x[keep], self.codes[keep], self.alive[keep]
+        return o2n
+
+    def stats(self):
+        return {"rows": len(self.x), "fallback_used": 0, "max_query_cands": 0}
+
     def save(self, directory):
         import os
         os.makedirs(directory, exist_ok=True)

@@ -108,7 +108,7 @@ async def run_store_scenarios(s):
             assert "Failed to upsert vectors to code_chunks" in str(e)
 
         # snapshot / restore (stands in for the Qdrant volume): the stored image goes to disk and back VERBATIM -- same ids,
-        # bit-identical scores, deleted points stay deleted, row numbers unchanged; plain files only (raw arrays + JSON lines)
+        # bit-identical scores, deleted points stay deleted, row numbers unchanged; plain files only (raw arrays + small JSON dictionaries)
         import os
         import tempfile
         before = await s.search("code_chunks", q.tolist(), limit=25, filters={"language": "python"})
@@ -118,7 +118,7 @@ async def run_store_scenarios(s):
         with tempfile.TemporaryDirectory() as snap:
             await s.save(snap)
             names = sorted(os.listdir(os.path.join(snap, "code_chunks")))
-            assert {"ids.jsonl", "payloads.jsonl", "collection.json"} <= set(names)
+            assert {"ids.fp.u8", "payloads.json", "col.content.blob", "col.file_path.i32", "collection.json"} <= set(names)
             assert not any(n.endswith((".npz", ".pkl", ".pickle")) for n in names)
             await s.load(snap)
         info = await s.get_collection_info("code_chunks")

@@ -1,0 +1,59 @@
+"""BASELINE configs[1] as ONE pipeline at reduced size (bench.py's `c2` leg, the same code): synthetic chunks -> packed HIP
+encoder -> device-to-device crh_index_append -> exact top-k over the EMBEDDED vectors, bit-exact against oracle/search on those
+vectors for both stores; then the GPU pipeline end to end against the fp32 pipeline on both weight statistics.  Also pins the
+fp32 torch graph of oracle/encoder.py evaluated on the GPU (what the end-to-end comparison uses to afford thousands of chunks)
+against its CPU evaluation.  Reference path: embeddings/indexer.py:66-85, query/vector_search.py:60-116,
+providers/unixcoder_provider.py:137-155."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c2_pipeline_at_reduced_size(gpu):
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd import ffi
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.c2_leg(np, torch, ffi, 0, 6000, 0, 64, 100, 400)
+    for store in ("bf16_store", "f32_store"):
+        p = r["parity"][store]
+        assert p["ids_bit_exact"] and p["scores_bit_exact"], (store, p)
+        st = p["search_stats"]
+        assert st["rows"] > 0 and st["candidates"] >= 64 * 100 and st["fallback_used"] in (0, 1)
+    assert r["value"] > 0 and r["search"]["ms_per_batch"] > 0
+    assert r["perturbed_chunk_queries_find_their_chunk_top1"] >= 0.9     # a chunk with a tenth of its tokens replaced retrieves the chunk
+    # encoder outputs are nothing like the Gaussian corpus: a common direction carries most of every vector
+    assert r["embedding_geometry"]["norm_of_mean_unit_vector"] > 0.2
+    e2e = r["end_to_end_vs_fp32_pipeline"]
+    print({k: v for k, v in e2e.items() if k != "what"})
+    # HF-init statistics: embeddings agree with fp32 to 1.5e-5 of cosine, every returned id scores within 1e-3 of the fp32
+    # pipeline's k-th score (north_star's bf16 criterion); ids near the cut-off still swap, because random-init encoders
+    # pack the top-100 cosines of a query within ~1e-3 of each other
+    h = e2e["hfinit"]
+    assert h["recall_at_100_within_1e-3_of_the_fp32_kth_score"] >= 0.999 and h["min_cosine_gpu_vs_fp32"] >= 0.9999 and h["max_abs_score_difference_by_rank"] <= 1e-3
+    assert h["recall_at_100"] >= 0.80
+    # deliberately sharp weights: every rounding amplified through 12 layers (tests/test_precision_budget.py)
+    sh = e2e["sharp"]
+    assert sh["recall_at_100"] >= 0.85 and sh["min_cosine_gpu_vs_fp32"] >= 0.995 and sh["recall_at_100_within_1e-3_of_the_fp32_kth_score"] >= 0.9
+
+
+def test_fp32_oracle_graph_on_gpu_equals_its_cpu_evaluation(gpu):
+    """oracle/encoder.forward(device='cuda') is the same plain-torch fp32 graph as the CPU oracle (rocBLAS fp32 instead of the
+    host BLAS): equal to ~1e-5 relative on both weight statistics, far inside the bf16 pipeline's own deviation."""
+    from oracle import encoder as oenc
+    cfg = oenc.EncoderConfig()
+    for init, lim in (("sharp", 2e-4), ("hf", 2e-5)):
+        w = oenc.random_weights(cfg, 23, init=init)
+        ids = oenc.synthetic_ids(cfg, [9, 40, 128, 300, 64, 17], seed=5)
+        ids[2, 20] = cfg.pad_token_id
+        a = oenc.forward(w, cfg, ids)
+        b = oenc.forward(w, cfg, ids, device="cuda:0")
+        rel = np.linalg.norm(a - b, axis=1) / np.linalg.norm(a, axis=1)
+        print(init, rel.max())
+        assert rel.max() <= lim

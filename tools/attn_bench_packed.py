@@ -22,11 +22,11 @@ for L in (40, 72, 100, 128, 150, 192, 208, 250, 256, 300, 320, 384, 450, 512):
     ts = []
     for rnd in range(5):
         for _ in range(3):
-            ffi.check(Lb.crh_attn_fwd_packed(qkv.data_ptr(), off.data_ptr(), km.data_ptr(), out.data_ptr(), B, Lmax, H, 0))
+            ffi.check(Lb.crh_attn_fwd_packed(qkv.data_ptr(), off.data_ptr(), km.data_ptr(), out.data_ptr(), B, T, Lmax, H, 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            ffi.check(Lb.crh_attn_fwd_packed(qkv.data_ptr(), off.data_ptr(), km.data_ptr(), out.data_ptr(), B, Lmax, H, 0))
+            ffi.check(Lb.crh_attn_fwd_packed(qkv.data_ptr(), off.data_ptr(), km.data_ptr(), out.data_ptr(), B, T, Lmax, H, 0))
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
     fl = 4.0 * B * H * L * L * 64
