@@ -185,8 +185,33 @@ def rehearse(args, json_fd) -> None:
     dt = time.perf_counter() - t0
     for r in range(world):        # rank r's record landed in slot r, both halves
         layout_ok = layout_ok and float(all_s[r, 0, 0]) == float(-r - (args.steps - 1)) and int(all_r[r, 0, 1]) == 1 + r * n_local
+    # the collectives of the legs an N > 1 run carries beside the headline (config5: the all-gather above + ONE all-reduce that
+    # completes the packed side columns -- every candidate is owned by exactly one rank, the others contribute zeros; embed: no
+    # data-path collective, barriers + max-over-ranks timing), with their layouts checked
+    legs = set(("config5", "embed") if args.legs is None else (x for x in args.legs.split(",") if x and x != "none"))
+    legs_ok = {}
+    if "config5" in legs:
+        n = B * K
+        words = n * (6 + ffi.RR_NAME_BYTES // 4)                       # ranking.device.PackedColumns: six int32 columns + 64 name bytes
+        cand = torch.arange(n, dtype=torch.int64)                       # candidate c is owned by rank c % world
+        packed = torch.zeros((words,), dtype=torch.int32)
+        mine = (cand % world) == rank
+        for c in range(6):
+            packed[c * n:(c + 1) * n][mine] = (cand[mine] * 7 + c).to(torch.int32)
+        packed[6 * n:].view(n, ffi.RR_NAME_BYTES // 4)[mine] = (cand[mine, None] + torch.arange(ffi.RR_NAME_BYTES // 4)[None, :]).to(torch.int32)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        ok = all(bool(torch.equal(packed[c * n:(c + 1) * n], (cand * 7 + c).to(torch.int32))) for c in range(6))
+        ok = ok and bool(torch.equal(packed[6 * n:].view(n, -1), (cand[:, None] + torch.arange(ffi.RR_NAME_BYTES // 4)[None, :]).to(torch.int32)))
+        legs_ok["config5"] = bool(ok)
+    if "embed" in legs:
+        dist.barrier()
+        te = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        legs_ok["embed"] = bool(abs(float(te.item()) - 0.001 * world) < 1e-12)
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    devices = [None] * world                              # (the real run fills these from crh_device_info: a mis-pinned rank shows)
+    dist.all_gather_object(devices, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_name": None, "hbm_bytes": None})
     ranks = torch.zeros((world,), dtype=torch.int64)
     dist.all_gather_into_tensor(ranks, torch.tensor([rank], dtype=torch.int64))
     per_rank = torch.zeros((world,), dtype=torch.float64)
@@ -198,11 +223,11 @@ def rehearse(args, json_fd) -> None:
                "config": {"workload": f"rehearsal: {world} gloo ranks, {B}x{K} exchange records, {n_local} rows per rank"},
                "backend": "gloo", "collective_ranks": int(len(set(ranks.tolist()))), "rccl_ranks": None,
                "exchange_layout_ok": bool(layout_ok), "per_rank_step_ms": [float(v) for v in per_rank.tolist()],
-               "rows_per_gpu": n_local}
+               "rows_per_gpu": n_local, "legs_rehearsed": legs_ok, "per_rank_device": devices}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.destroy_process_group()
-    if not layout_ok:
-        raise SystemExit("rehearsal: the gathered records are not laid out as [rank][scores | rows]")
+    if not layout_ok or not all(legs_ok.values()):
+        raise SystemExit(f"rehearsal: exchange layout ok = {layout_ok}, legs = {legs_ok}")
 
 
 # ------------------------------------------------------------------------------------------------ the measurement
@@ -404,7 +429,7 @@ def run(args, json_fd) -> None:
 
     # ---- what actually took part in the exchange (N>1): distinct ranks seen through a real all-gather, per-rank step times,
     # and the merged list against a sort of the gathered lists (score descending, lower global row first)
-    rccl_ranks, per_rank_ms, merge_ok = None, None, None
+    rccl_ranks, per_rank_ms, merge_ok, per_rank_device = None, None, None, None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -415,6 +440,12 @@ def run(args, json_fd) -> None:
         pr = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(pr, torch.tensor([float(np.median(per_step))], dtype=torch.float64, device=dev))
         per_rank_ms = [float(v) for v in pr.tolist()]
+        info = ffi.device_info(local_rank)
+        per_rank_device = [None] * dist.get_world_size()
+        me = {"rank": rank, "local_rank": local_rank, "device_name": info["name"], "arch": info["arch"], "hbm_bytes": info["hbm_bytes"],
+              "cu_count": info["cu_count"], "pci_bus_id": torch.cuda.get_device_properties(local_rank).pci_bus_id
+              if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None}
+        (dist._d if isinstance(dist, HostStagedCollectives) else dist).all_gather_object(per_rank_device, me)
         _, _, _, _, gat_s, gat_r = slots[last]
         cat_s = gat_s.permute(1, 0, 2).reshape(B, -1)
         cat_r = gat_r.permute(1, 0, 2).reshape(B, -1)
@@ -464,6 +495,7 @@ def run(args, json_fd) -> None:
         "roofline": roof,
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
+        "per_rank_device": per_rank_device,
         "rccl_ranks": rccl_ranks if args.backend == "nccl" else None,
         "collective_ranks": rccl_ranks, "backend": args.backend if dist is not None else None,
         "exchange_ms_device": (dict(pct(exchange), what="1 RCCL all-gather of the [scores | rows] records + k_merge_topk, rank 0")
@@ -657,6 +689,7 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    sharded = store_sharded_check(np, torch, dist, dev, rank, world)
     if rank != 0:
         return None
     # parity + host cost: HybridRanker over hit dicts rebuilt from the gathered (and, for N>1, all-reduced) columns
@@ -695,8 +728,50 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
             "ms_per_step": wall * 1e3, "steps": steps, "rerank_ms_per_batch": rerank * 1e3,
             "host_hybrid_ranker_ms_per_batch": t_host * 1e3, "survivors": survivors,
             "roofline": scan_roofline(N, 768, scan, launches),
+            "store_sharded": sharded,
             "parity": {"identical_to_host_hybrid_ranker": bool(ok), "queries": B,
                        "what": "survivors, order, f64 final scores, the four signals and the source label of every query"}}
+
+
+def store_sharded_check(np, torch, dist, dev, rank, world, n=20000, nq=16):
+    """The row-sharded index THROUGH the reference's store surface: HipVectorStore(shards=...) -- one process per GPU over the
+    run's process group at N > 1, three in-process shards on the one GPU at N = 1 -- upsert of payload dictionaries, graph
+    degrees, search_rerank_batch (per-shard scans -> [all-gather ->] crh_merge_topk_strided -> side columns summed over the
+    shards -> crh_rerank_vector), compared with the same calls on an unsharded store and with the host HybridRanker."""
+    import asyncio
+    from coderag_amd.engine_helpers import search_and_rank_batch_device
+    from coderag_amd.query_types import ExtractedEntity, QueryIntent, QueryPlan
+    from coderag_amd.ranking import HybridRanker
+    from coderag_amd.ranking.device import DeviceReranker
+    from coderag_amd.store import HipVectorStore
+    if dist is not None and isinstance(dist, HostStagedCollectives):
+        return {"skipped": "gloo rehearsal on a shared GPU: the store's dist backend issues device collectives"}
+    rng = np.random.default_rng(2025)                      # the same stream on every rank: replicated calls
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    pay = [{"file_path": f"/p/f{i % 500}.py", "entity_type": "function", "entity_name": f"fn_{i % 900}", "language": "python", "start_line": i % 37,
+            "end_line": i % 37 + 5, "content": "x" * int(c), "graph_node_id": None if i % 3 else f"m.fn_{i % 900}", "content_hash": "h",
+            "project_name": "p"} for i, c in enumerate(rng.integers(0, 3000, n))]
+    qs = rng.standard_normal((nq, 768)).astype(np.float32)
+    intents = list(QueryIntent)
+    plans = [QueryPlan(f"q{i}", intents[i % len(intents)], entities=[ExtractedEntity(f"fn_{37 * i % 900}"), ExtractedEntity("fn")]) for i in range(nq)]
+    multi = dist is not None and world > 1
+    ns, backend = (world, "dist") if multi else (3, "local")
+
+    async def go(shards, backend):
+        async with HipVectorStore(dim=768, dtype="bf16", initial_capacity=4096, device=dev.index, shards=shards, shard_backend=backend) as st:
+            await st.create_collections()
+            for a in range(0, n, 5000):
+                await st.upsert("code_chunks", [f"id{i}" for i in range(a, a + 5000)], vecs[a:a + 5000], pay[a:a + 5000])
+            await st.set_graph_degrees("code_chunks", {f"m.fn_{j}": j % 60 for j in range(0, 900, 2)})
+            ranked = await search_and_rank_batch_device(st, DeviceReranker(device=dev.index), HybridRanker(), qs, plans, limit=20)
+            info = await st.get_collection_info("code_chunks")
+            return [[(r.file_path, r.entity_name, r.start_line, r.final_score, r.source, tuple(sorted(r.signal_scores.items()))) for r in per] for per in ranked], info
+    t0 = time.perf_counter()
+    got, info = asyncio.run(go(ns, backend))
+    ref, _ = asyncio.run(go(1, "local"))
+    return {"shards": ns, "backend": backend, "rows": n, "shard_rows": info.config["shard_rows"], "queries": nq,
+            "identical_to_unsharded_store": bool(got == ref and all(len(p) > 0 for p in got)), "seconds": time.perf_counter() - t0,
+            "what": "HipVectorStore(shards=N).search_rerank_batch vs the same calls on shards=1: survivors, order, f64 scores, signals, source"}
 
 
 # ------------------------------------------------------------------------------------------------ encoder legs

@@ -18,6 +18,7 @@ import json
 import math
 import os
 import re
+import threading
 import zlib
 from dataclasses import dataclass
 
@@ -175,6 +176,8 @@ class HipUniXcoder:
                 ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32)))
         # raw addresses, taken once: a forward is 62 launches with ~10 pointer arguments each, and on the one-query path the
         # host's enqueue time is as long as the GPU's chain of kernels
+        # models are shared process-wide (load_unixcoder) while the pinned staging slots below are per model: one submission at a time
+        self._submit_lock = threading.Lock()
         self._emb_ptrs = tuple(int(t.data_ptr()) for t in (self.word, self.pos, self.type0, self.emb_g, self.emb_b))
         self._layer_ptrs = [{k: int(v.data_ptr()) for k, v in ly.items()} for ly in self.layers]
 
@@ -305,6 +308,10 @@ class HipUniXcoder:
         ids of ALL batches back to back, their row offsets, the scatter order -- goes up in THREE asynchronous copies from
         pinned memory before the first kernel, so the host never waits on the stream while it enqueues (a pageable copy per
         batch kept the host in lockstep with the GPU, and nothing else could overlap with it).  Returns f32 CUDA [n, 768]."""
+        with self._submit_lock:      # (two providers / a query thread beside an indexing thread share this model's pinned slots)
+            return self._embed_packed_locked(batches, lens, fill, n)
+
+    def _embed_packed_locked(self, batches, lens, fill, n: int):
         torch = self._torch
         ffi.use_device(self.device.index)
         total = int(sum(int(lens[i]) for rows, _ in batches for i in rows))

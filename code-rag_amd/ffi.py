@@ -330,6 +330,12 @@ class Index:
         ntiles = (rows + 31) // 32
         tile_bytes = self.dim // 16 * 1024
         os.makedirs(directory, exist_ok=True)
+        # index.json is what makes a directory a snapshot: it goes away first and comes back last (os.replace), carrying the size
+        # of every data file, so a save that died half way leaves no directory load() would accept
+        try:
+            os.remove(os.path.join(directory, "index.json"))
+        except FileNotFoundError:
+            pass
         meta = {"format": self.SNAPSHOT_FORMAT, "dim": self.dim, "dtype": "bf16" if self.dtype == DTYPE_BF16 else "f32",
                 "rows": rows, "alive": alive, "tiles": ntiles, "n_code_cols": self.n_code_cols, "tile_bytes": tile_bytes,
                 "files": {"tiles": "tiles.bin", "alive": "alive.u32", "codes": "codes.i32" if self.n_code_cols else None,
@@ -356,8 +362,12 @@ class Index:
             if m is not None:
                 m.flush()
         del tiles, al, master, codes
-        with open(os.path.join(directory, "index.json"), "w") as f:
+        meta["sizes"] = {name: os.path.getsize(os.path.join(directory, name)) for name in meta["files"].values() if name}
+        with open(os.path.join(directory, "index.json.tmp"), "w") as f:
             json.dump(meta, f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(os.path.join(directory, "index.json.tmp"), os.path.join(directory, "index.json"))
         return meta
 
     def load(self, directory: str) -> dict:
@@ -376,6 +386,9 @@ class Index:
         rows, ntiles, tile_bytes = int(meta["rows"]), int(meta["tiles"]), int(meta["tile_bytes"])
         if ntiles != (rows + 31) // 32 or tile_bytes != self.dim // 16 * 1024:
             raise NativeError(E_INVALID, f"snapshot {directory}: inconsistent index.json")
+        for name, size in (meta.get("sizes") or {}).items():
+            if os.path.getsize(os.path.join(directory, name)) != int(size):
+                raise NativeError(E_INVALID, f"snapshot file {os.path.join(directory, name)} is not the size index.json recorded")
         if rows == 0:
             return meta
         self.reserve(rows)

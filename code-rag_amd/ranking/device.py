@@ -22,6 +22,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import struct
+import threading
 from dataclasses import dataclass
 from typing import Any, Sequence
 
@@ -249,8 +250,13 @@ class DeviceReranker:
         self.config = config or RankingConfig()
         self.centrality_top = centrality_top   # QueryEngine looks up the first 5 vector hits (engine.py:358-362)
         self.device = torch.device("cuda", device)
+        self._lock = threading.Lock()          # the cached device / pinned output buffers below serve one call at a time
 
     def rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None) -> RerankOutput:
+        with self._lock:
+            return self._rank(scores_dev, rows_dev, cols, plans, stream)
+
+    def _rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None) -> RerankOutput:
         t = self._torch
         ffi.use_device(self.device.index)
         stream = ffi.current_stream(self.device) if stream is None else stream

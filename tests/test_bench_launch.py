@@ -30,6 +30,20 @@ def test_self_launch_prints_one_json_line_with_all_ranks(n, scaling):
     assert rec["rows_per_gpu"] == (4096 // n if scaling == "strong" else 4096)
 
 
+def test_eight_ranks_strong_scaling_with_the_config5_and_embed_collectives():
+    """The shape of the first real 8-GPU record (SCALE_rNN): 8 ranks, --scaling strong, the config5 and embed legs beside the
+    headline -- every collective those legs issue runs (gloo) and its layout is checked; per-rank device records are there."""
+    p = _run("--gpus", "8", "--backend", "gloo", "--rows", "80000", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--legs", "config5,embed")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["collective_ranks"] == 8 and rec["exchange_layout_ok"] is True
+    assert rec["legs_rehearsed"] == {"config5": True, "embed": True}
+    assert rec["rows_per_gpu"] == 10000 and rec["scaling"] == "strong" and len(rec["per_rank_step_ms"]) == 8
+    assert [d["rank"] for d in rec["per_rank_device"]] == list(range(8)) and sorted(d["local_rank"] for d in rec["per_rank_device"]) == list(range(8))
+
+
 def test_world_size_mismatch_is_refused():
     p = _run("--gpus", "2", "--backend", "gloo", env_extra={"WORLD_SIZE": "3", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)

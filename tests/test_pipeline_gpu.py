@@ -86,3 +86,62 @@ def test_index_search_rank_roundtrip(gpu, tmp_path):
             assert again == hits
     asyncio.run(go())
     assert provider.submissions >= 1
+
+
+def test_reindexing_the_same_files_five_times_does_not_grow_the_index(gpu):
+    """The reference's indexing flow deletes and re-inserts every chunk of a file on every run (embeddings/indexer.py:61-64,
+    called with force=True from pipeline/orchestrator.py:630-650).  200 files re-indexed five times through
+    VectorIndexer.index_file(force=True): the store compacts by itself, the scan reads only live rows afterwards
+    (crh_search_stats.rows == alive rows), and search results are bit-identical to a store built once from the same files."""
+    import coderag_amd  # noqa: F401
+    from coderag_amd.embedder import Embedder
+    from coderag_amd.indexer import CodeChunker, VectorIndexer
+    from coderag_amd.providers import HipUniXcoderProvider, ProviderConfig
+    from coderag_amd.store import HipVectorStore
+    from coderag_amd.vector_search import VectorSearcher
+
+    provider = HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model="synthetic", extra={"synthetic_weights": 5, "num_layers": 2}))
+    embedder = Embedder(provider_instance=provider)
+    files = [_parsed_file(f"/proj/pkg{f % 7}/mod{f}.py", [(f"fn_{f}_{i}", f"def fn_{f}_{i}(x):\n    y = x * {i} + {f}\n    return helper_{i % 3}(y)\n" * (1 + i % 3))
+                                                          for i in range(4)]) for f in range(200)]
+    queries = [files[f].all_entities[f % 4].code for f in (3, 77, 150, 199)]
+
+    async def build(rounds, **kw):
+        async with HipVectorStore(dim=embedder.embedding_dim, dtype="f32", initial_capacity=256, **kw) as store:
+            await store.create_collections()
+            indexer = VectorIndexer(store, embedder, CodeChunker(max_tokens=1000, overlap_tokens=200))
+            for _ in range(rounds):
+                for f in files:
+                    assert await indexer.index_file(f, force=True, project_name="proj") == 4
+            info = await store.get_collection_info("code_chunks")
+            searcher = VectorSearcher(store, embedder)
+            hits = [await searcher.search_code(q, limit=10) for q in queries]
+            col = store._col("code_chunks")
+            return info, hits, col.shards.stats()["rows"], col.payloads.n, col.ids.n
+
+    info5, hits5, scanned5, pn5, in5 = asyncio.run(build(5, compact_dead_fraction=0.25, compact_min_dead=100))
+    info1, hits1, scanned1, _, _ = asyncio.run(build(1))
+    assert info5.points_count == info1.points_count == 800
+    assert info5.config["compactions"] >= 2 and info5.config["rows_appended"] < 2 * 800         # dead rows were reclaimed on the way
+    assert pn5 == in5 == info5.config["rows_appended"]                                         # ... in the host tables too
+    assert hits5 == hits1                                                                      # same ids' payloads, same score bits
+    # an explicit compaction leaves exactly the alive rows for the scan to stream
+    async def compacted():
+        async with HipVectorStore(dim=embedder.embedding_dim, dtype="f32", initial_capacity=256, compact_dead_fraction=0.0) as store:
+            await store.create_collections()
+            indexer = VectorIndexer(store, embedder, CodeChunker(max_tokens=1000, overlap_tokens=200))
+            for _ in range(3):
+                for f in files[:50]:
+                    await indexer.index_file(f, force=True, project_name="proj")
+            assert (await store.get_collection_info("code_chunks")).config["rows_appended"] == 600     # never compacted: 3 x 200 rows
+            assert await store.compact("code_chunks") == 400
+            searcher = VectorSearcher(store, embedder)
+            await searcher.search_code(queries[0], limit=5)
+            st = store._col("code_chunks").shards.stats()
+            assert st["rows"] == 200 == (await store.get_collection_info("code_chunks")).points_count
+            import os, tempfile
+            with tempfile.TemporaryDirectory() as d:
+                await store.save(d)
+                n = np.fromfile(os.path.join(d, "code_chunks", "alive.u32"), np.uint32)
+                assert int(sum(bin(int(w)).count("1") for w in n)) == 200 and len(n) == 7       # 200 rows = 7 tiles, every stored row alive
+    asyncio.run(compacted())

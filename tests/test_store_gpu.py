@@ -48,3 +48,66 @@ def test_golden_search_cases_on_hip_index(gpu):
             assert np.array_equal(r, gold[f"{tag}/rows"]), tag
             assert np.array_equal(s.view(np.uint32), gold[f"{tag}/scores"].view(np.uint32)), tag
             idx.close()
+
+
+def test_store_scenarios_with_three_shards_on_hip_index(gpu):
+    """HipVectorStore(shards=3), all shards on device 0 (what a one-GPU box can run): per-shard crh_search with row_base ->
+    crh_merge_topk_strided on the device; filters / deletes / update check fan out; same scenarios, same answers."""
+    import coderag_amd  # noqa: F401
+    from coderag_amd.store import CollectionName, HipVectorStore, QdrantManager
+    from tests.store_scenarios import run_reference_database_scenario, run_store_scenarios
+    asyncio.run(run_store_scenarios(HipVectorStore(dim=768, dtype="f32", initial_capacity=64, device=0, shards=3)))
+    asyncio.run(run_reference_database_scenario(QdrantManager(dim=1536, dtype="f32", shards=3), CollectionName))
+
+
+def test_sharded_hip_store_equals_the_unsharded_one(gpu, monkeypatch):
+    """The life of a collection of tests/test_store_sharded.py (bulk upsert in blocks over the shards, filters, replace, the
+    reference's delete-then-reinsert re-index, raw-client delete, auto + explicit compaction, snapshot) on the real index with
+    1, 2 and 3 shards: identical ids, f32 score bits and payloads throughout."""
+    import coderag_amd  # noqa: F401
+    from coderag_amd import shards as shards_mod
+    from coderag_amd.store import HipVectorStore
+    from tests.test_store_sharded import drive
+    orig = shards_mod.ShardSet.__init__
+
+    def small_blocks(self, *a, **kw):
+        kw["block"] = 64
+        orig(self, *a, **kw)
+    monkeypatch.setattr(shards_mod.ShardSet, "__init__", small_blocks)
+    logs = {}
+    for ns in (1, 2, 3):
+        logs[ns] = []
+        asyncio.run(drive(HipVectorStore(dim=768, dtype="f32", initial_capacity=64, device=0, shards=ns, compact_dead_fraction=0.2,
+                                         compact_min_dead=50), logs[ns]))
+    assert logs[1] == logs[2] == logs[3] and len(logs[1]) > 25
+
+
+def test_sharded_device_rerank_equals_the_host_ranker(gpu):
+    """search_rerank_batch over three shards: per-shard scans -> device merge -> side columns gathered per shard and summed ->
+    crh_rerank_vector; equal to the host HybridRanker on the same hits, and to the unsharded store."""
+    import numpy as np
+    import coderag_amd  # noqa: F401
+    from coderag_amd.engine_helpers import search_and_rank_batch_device
+    from coderag_amd.query_types import ExtractedEntity, QueryIntent, QueryPlan
+    from coderag_amd.ranking import HybridRanker
+    from coderag_amd.ranking.device import DeviceReranker
+    from coderag_amd.store import HipVectorStore
+    rng = np.random.default_rng(3)
+    n = 700
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    pay = [{"file_path": f"/p/f{i % 40}.py", "entity_type": "function", "entity_name": f"fn_{i % 90}", "language": "python", "start_line": i % 17,
+            "end_line": i % 17 + 5, "content": "x" * int(rng.integers(0, 3000)), "graph_node_id": None if i % 3 else f"m.fn_{i % 90}",
+            "content_hash": "h", "project_name": "p"} for i in range(n)]
+    qs = rng.standard_normal((8, 768)).astype(np.float32)
+    plans = [QueryPlan(f"q{i}", list(QueryIntent)[i % len(QueryIntent)], entities=[ExtractedEntity(f"fn_{7 * i % 90}"), ExtractedEntity("fn")]) for i in range(8)]
+    out = {}
+    for ns in (1, 3):
+        async def go(ns=ns):
+            async with HipVectorStore(dim=768, dtype="f32", initial_capacity=64, device=0, shards=ns) as s:
+                await s.create_collections()
+                await s.upsert("code_chunks", [f"id{i}" for i in range(n)], vecs, pay)
+                await s.set_graph_degrees("code_chunks", {f"m.fn_{j}": j for j in range(0, 90, 2)})
+                return await search_and_rank_batch_device(s, DeviceReranker(device=0), HybridRanker(), qs, plans, limit=20)
+        ranked = asyncio.run(go())
+        out[ns] = [[(r.file_path, r.entity_name, r.start_line, r.final_score, r.source, tuple(sorted(r.signal_scores.items()))) for r in per] for per in ranked]
+    assert out[1] == out[3] and all(len(per) > 0 for per in out[1])
