@@ -820,6 +820,8 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
            "data": "synthetic ids + seeded random RoBERTa-base-geometry weights (no checkpoint offline)",
            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops": flops}}
+    if rank == 0:
+        res["ceiling"] = encoder_ceiling(np, torch, dev, [int(b[0].numel()) for b in batches], n_chunks, flops, dt, cfg)
     if cpu and rank == 0:
         from oracle import encoder as orc
         ocfg = orc.EncoderConfig()
@@ -985,6 +987,44 @@ def c2_leg(np, torch, ffi, local_rank, n_chunks, rank, B, K, parity_chunks):
     res["end_to_end_vs_fp32_pipeline"] = dict(e2e, what="GPU: bf16 HIP encoder -> bf16 HIP store -> crh_search; reference side: oracle/encoder.py in fp32 "
                                               "(torch fp32 on the GPU for speed; pinned to its CPU evaluation by tests/test_c2_gpu.py) -> oracle f32 cosine search")
     return res
+
+
+def encoder_ceiling(np, torch, dev, batch_tokens, n_chunks, flops, dt, cfg):
+    """A practical bound for the encoder leg beside the 2.5 PFLOP/s of the roofline: per layer, the four GEMMs at the rate the
+    vendor library (hipBLASLt through torch.nn.functional.linear, bf16, bias only -- no GELU, no residual) reaches on the same
+    shapes ON THIS DEVICE, plus attention and the two LayerNorms at their HBM bound (every byte they must move, once, at the
+    8 TB/s of the search roofline).  Measured here, outside every timed region; nothing of it is used by the product path."""
+    H, F = cfg.hidden_size, cfg.intermediate_size
+    T = int(np.median(batch_tokens))
+    shapes = {"qkv": (3 * H, H), "oproj": (H, H), "ffn1": (F, H), "ffn2": (H, F)}
+    g = torch.Generator(device=dev).manual_seed(3)
+    us = {}
+    for name, (N, K) in shapes.items():
+        a = torch.randn((T, K), generator=g, device=dev).to(torch.bfloat16)
+        w = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(torch.bfloat16)
+        b = torch.randn((N,), generator=g, device=dev).to(torch.bfloat16)
+        for _ in range(3):
+            torch.nn.functional.linear(a, w, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.nn.functional.linear(a, w, b)
+        e1.record()
+        torch.cuda.synchronize()
+        us[name] = e0.elapsed_time(e1) / 10 * 1e3
+        del a, w, b
+    gemm_s_per_token = sum(us.values()) * 1e-6 / T
+    attn_bytes = (3 * H + H) * 2                      # per token and layer: QKV read once, context written once
+    ln_bytes = (3 + 2) * H * 2                        # LayerNorm(x + residual): two reads + a write; LayerNorm: a read + a write
+    hbm_s_per_token = (attn_bytes + ln_bytes) / (HBM_PEAK_GBS * 1e9)
+    total_tokens = float(sum(batch_tokens))
+    ceil_s = cfg.num_layers * total_tokens * (gemm_s_per_token + hbm_s_per_token)
+    return {"seconds": ceil_s, "chunks_per_s": n_chunks / ceil_s, "tflops": flops / ceil_s / 1e12, "frac_of_mfma_peak": flops / ceil_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "achieved_frac_of_ceiling": ceil_s / dt, "vendor_gemm_us_at_T": dict(us, T=T),
+            "vendor_gemm_tflops": {k: 2.0 * T * shapes[k][0] * shapes[k][1] / (v * 1e-6) / 1e12 for k, v in us.items()},
+            "hbm_bound_us_per_layer_at_T": {"attention": attn_bytes * T / (HBM_PEAK_GBS * 1e3), "layernorms": ln_bytes * T / (HBM_PEAK_GBS * 1e3)},
+            "what": "sum over layers of [4 GEMMs at the vendor library's measured rate on these shapes (bias only) + attention and LayerNorm "
+                    "bytes at 8 TB/s]; embedding gather, pool and launch gaps count as zero"}
 
 
 def _source_files():

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""HipVectorStore's host side at the sizes its device side is built for: upsert rate with ndarray / CUDA
-vectors and payload dictionaries, delete-by-file_path of 1 % of the rows, the update check, a filtered search -- on N synthetic
-chunks (default 5M, bf16 store).  python tools/store_scale_bench.py [rows] -> one JSON line."""
+"""HipVectorStore's host side at the sizes its device side is built for: upsert rate with ndarray / CUDA vectors and payload
+dictionaries (uuid4-shaped ids, 400-character contents), delete-by-file_path of 1 % of the rows, the update check, a filtered
+search; then half of the files deleted -> batch-64 scan time before / after HipVectorStore.compact() (crh_index_compact + the
+columnar host tables), snapshot save / load of the whole store, resident host memory -- on N synthetic chunks (default 5M,
+bf16 store).  python tools/store_scale_bench.py [rows] [snapshot dir] -> one JSON line."""
 import asyncio
 import json
 import os
@@ -21,8 +23,42 @@ n_files = 100                                   # one file = 1 % of the rows
 dev = torch.device("cuda:0")
 
 
+body = "def f(x):\n    return x  # " + "lorem ipsum " * 31            # ~400 characters per chunk
+
+
+def uid(i: int) -> str:
+    h = f"{(i * 0x9E3779B97F4A7C15 + 0x1234567) & ((1 << 128) - 1):032x}"
+    return f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}"
+
+
+def rss_gb() -> float:
+    import psutil
+    return psutil.Process().memory_info().rss / 2**30
+
+
+async def scan_ms(s, steps=10):
+    """Device time of a 64-query batch top-100 through the collection's index (what the headline bench measures)."""
+    idx = s._col("code_chunks").index
+    qd = torch.randn((64, 768), device=dev)
+    out_s = torch.empty((64, 100), dtype=torch.float32, device=dev)
+    out_r = torch.empty((64, 100), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        idx.search(qd, 100, out_scores=out_s, out_rows=out_r, stream=st)
+    idx.search_finish(st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        idx.search(qd, 100, out_scores=out_s, out_rows=out_r, stream=st)
+    e1.record()
+    idx.search_finish(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, idx.stats()["rows"] // (steps + 0)
+
+
 async def main():
-    s = HipVectorStore(dim=768, dtype="bf16", initial_capacity=rows)
+    s = HipVectorStore(dim=768, dtype="bf16", initial_capacity=rows + batch, compact_dead_fraction=0.0)      # (compaction is timed explicitly below)
     await s.connect()
     await s.create_collections()
     gen = torch.Generator(device=dev)
@@ -31,9 +67,9 @@ async def main():
     for r0 in range(0, rows, batch):
         m = min(batch, rows - r0)
         t0 = time.perf_counter()
-        ids = [f"{i:032x}" for i in range(r0, r0 + m)]
-        payloads = [{"file_path": f"/repo/src/f{i % n_files}.py", "entity_type": "function", "entity_name": f"fn_{i}", "language": "python",
-                     "start_line": i % 900, "end_line": i % 900 + 20, "content": "def f(): pass", "graph_node_id": None,
+        ids = [uid(i) for i in range(r0, r0 + m)]
+        payloads = [{"file_path": f"/repo/src/f{i % n_files}.py", "entity_type": "function", "entity_name": f"fn_{i % 50000}", "language": "python",
+                     "start_line": i % 900, "end_line": i % 900 + 20, "content": body + str(i), "graph_node_id": None,
                      "content_hash": f"h{i % n_files}", "project_name": "bench"} for i in range(r0, r0 + m)]
         t_pay += time.perf_counter() - t0
         x = torch.randn((m, 768), generator=gen, device=dev)
@@ -71,6 +107,54 @@ async def main():
            "file_needs_update_answer": fresh, "delete_by_file_path_ms": t_del * 1e3, "rows_deleted": before - after,
            "deleted_fraction": (before - after) / before, "hits_before_delete": len(hits), "hits_after_delete": len(gone),
            "delete_by_project_ms": t_del2 * 1e3, "points_left": (await s.get_collection_info("code_chunks")).points_count}
+    col = s._col("code_chunks")
+    out["host_tables_bytes"] = {"ids": col.ids.nbytes(), "payload_columns": col.payloads.nbytes()}
+    out["rss_gb_after_build"] = rss_gb()
+    # ---- snapshot of the whole store at full size (index image + id / payload tables), then restore
+    snap = sys.argv[2] if len(sys.argv) > 2 else "/dev/shm/coderag_store_snap"
+    probe_q = np.random.default_rng(9).standard_normal(768).astype(np.float32).tolist()
+    live = await s.search("code_chunks", probe_q, limit=20)
+    t0 = time.perf_counter()
+    await s.save(snap)
+    t_save = time.perf_counter() - t0
+    size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(snap) for f in fs)
+    t0 = time.perf_counter()
+    await s.load(snap)
+    t_load = time.perf_counter() - t0
+    out["snapshot_full"] = {"rows": (await s.get_collection_info("code_chunks")).config["rows_appended"], "save_seconds": t_save, "load_seconds": t_load,
+                            "bytes": size, "directory": snap, "same_hits_after_restore": (await s.search("code_chunks", probe_q, limit=20)) == live}
+    out["rss_gb_after_restore"] = rss_gb()
+    # ---- half of the files deleted (the state four re-index runs without compaction would leave is worse): scan before / after
+    ms_full, _ = await scan_ms(s)
+    for f in range(0, n_files, 2):
+        await s.delete("code_chunks", {"file_path": f"/repo/src/f{f}.py"})
+    info = await s.get_collection_info("code_chunks")
+    ms_dead, _ = await scan_ms(s)
+    keep_q = np.random.default_rng(9).standard_normal(768).astype(np.float32).tolist()
+    before = await s.search("code_chunks", keep_q, limit=20)
+    t0 = time.perf_counter()
+    reclaimed = await s.compact("code_chunks")
+    t_compact = time.perf_counter() - t0
+    after = await s.search("code_chunks", keep_q, limit=20)
+    ms_compact, _ = await scan_ms(s)
+    info2 = await s.get_collection_info("code_chunks")
+    out["compaction"] = {"rows_before": info.config["rows_appended"], "alive": info.points_count, "rows_reclaimed": reclaimed, "seconds": t_compact,
+                         "scan_ms_all_alive": ms_full, "scan_ms_half_dead": ms_dead, "scan_ms_after_compaction": ms_compact,
+                         "rows_after": info2.config["rows_appended"], "same_hits_before_and_after": before == after}
+    # ---- and the compacted store
+    t0 = time.perf_counter()
+    await s.save(snap)
+    t_save = time.perf_counter() - t0
+    size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(snap) for f in fs)
+    t0 = time.perf_counter()
+    await s.load(snap)
+    t_load = time.perf_counter() - t0
+    again = await s.search("code_chunks", keep_q, limit=20)
+    out["snapshot_compacted"] = {"rows": info2.config["rows_appended"], "save_seconds": t_save, "load_seconds": t_load, "bytes": size, "directory": snap,
+                       "same_hits_after_restore": again == after}
+    out["rss_gb_end"] = rss_gb()
+    import shutil
+    shutil.rmtree(snap, ignore_errors=True)
     await s.close()
     print(json.dumps(out))
 
