@@ -568,20 +568,9 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 template <int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv, const unsigned long long *__restrict__ kmask,
                                                   bf16_t *__restrict__ out, int Lpad, int H, float scale_log2,
-                                                  const int32_t *__restrict__ row_off, int T, int skew, int first_gen)
+                                                  const int32_t *__restrict__ row_off, int T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kv[];
-    // De-phasing.  A workgroup stages its K/V (memory), meets at a barrier, computes and exits; the workgroups that share a CU are
-    // launched together and take equally long, so left alone they stay in step for the whole kernel -- the CU alternates between
-    // "everyone loads" and "everyone computes" and only ~25 us of the ~60 us of memory time hide under compute
-    // (profiles/r02_attention.md).  The workgroups of the FIRST generation (one per resident slot) therefore start `skew` x
-    // 1024 cycles apart by their slot on the CU (read off the LDS base the hardware gave them); every later workgroup takes over a
-    // slot when its predecessor exits and inherits the offset.
-    if (skew > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < first_gen) {
-        const unsigned alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);      // HW_REG_LDS_ALLOC: base [7:0], size [20:12], same granule
-        const unsigned size = (alloc >> 12) & 0x1ffu, slot = size ? (alloc & 0xffu) / size : 0u;
-        for (unsigned i = 0; i < slot * (unsigned)skew; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     unsigned char *Ks = kv, *Vs = kv + (size_t)((Lpad + 63) & ~63) * 128;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -927,10 +916,6 @@ using namespace crh;
 using namespace crh::enc;
 
 namespace {
-// start offsets between the workgroups sharing a CU (k_attn) / between neighbouring CUs (k_gemm_pp), in units of 1024 cycles;
-// 0 = everybody starts together.  The debug build can change them at run time (crh_debug_set_skew, tools/skew_sweep.py).
-int g_attn_skew = 0, g_gemm_skew = 0;
-
 // Grid: a multiple of 8 workgroups (one XCD label each).  Default: persistent, capped at the CU count, each workgroup walking
 // several tiles with one pipeline (whole forward 9.06 vs 9.29 ms against one workgroup per tile, same process, B=256 L=128;
 // the two are within a few percent -- CODERAG_HIP_GEMM_PERSISTENT=0 selects one workgroup per tile).
@@ -1014,11 +999,11 @@ int launch_gemm256(int epi, const void *x, const void *w, const float *bias, con
     const bf16_t *xa = (const bf16_t *)x, *wa = (const bf16_t *)w, *ra = (const bf16_t *)res;
     bf16_t *ya = (bf16_t *)y;
     if (epi == 0)
-        hipLaunchKernelGGL((g256::k_gemm_pp<0>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, g_gemm_skew);
+        hipLaunchKernelGGL((g256::k_gemm_pp<0>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
     else if (epi == 1)
-        hipLaunchKernelGGL((g256::k_gemm_pp<1>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, g_gemm_skew);
+        hipLaunchKernelGGL((g256::k_gemm_pp<1>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
     else
-        hipLaunchKernelGGL((g256::k_gemm_pp<2>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, g_gemm_skew);
+        hipLaunchKernelGGL((g256::k_gemm_pp<2>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -1084,7 +1069,7 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
         if (N % g256::BN || K % (2 * g256::BK) || K < 4 * g256::BK || (int64_t)T * K * 2 >= (1LL << 32)) return fail(CRH_E_INVALID, "debug gemm: bad shape");
         const dim3 grid256(gemm256_grid(T, N)), block(g256::WAVES * 64);
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
-        hipLaunchKernelGGL((g256::k_gemm_pp<0, 6>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K, g_gemm_skew);
+        hipLaunchKernelGGL((g256::k_gemm_pp<0, 6>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     }
@@ -1094,10 +1079,10 @@ int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void
         const dim3 grid256(gemm256_grid(T, N)), block(g256::WAVES * 64);
         if (variant == 17) {
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
-            hipLaunchKernelGGL((g256::k_gemm_pp<0, 1>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K, g_gemm_skew);
+            hipLaunchKernelGGL((g256::k_gemm_pp<0, 1>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
         } else {
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
-            hipLaunchKernelGGL((g256::k_gemm_pp<0, 2>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K, g_gemm_skew);
+            hipLaunchKernelGGL((g256::k_gemm_pp<0, 2>), grid256, block, g256::kLds, st, (const bf16_t *)x, (const bf16_t *)w, bias, (const bf16_t *)nullptr, (bf16_t *)y, T, N, K);
         }
         CRH_HIP(hipGetLastError());
         return CRH_OK;
@@ -1161,15 +1146,6 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
 }
 
 static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const int32_t *row_off, int B, int T, int L, int H, void *stream);
-
-#ifdef CRH_ENABLE_DEBUG
-int crh_debug_set_skew(int attn_units, int gemm_units)
-{
-    g_attn_skew = attn_units < 0 ? 0 : attn_units;
-    g_gemm_skew = gemm_units < 0 ? 0 : gemm_units;
-    return CRH_OK;
-}
-#endif
 
 // ---- verdict of the device-side row_off checks: one word per device in pinned host memory (the kernel ORs into it at system
 // scope; the host peeks at it without synchronising).  Bits: see k_check_row_off.
@@ -1238,8 +1214,7 @@ static int attn_launch(const void *qkv, const uint64_t *kmask, void *out, const 
             CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn<NW_, QT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 256)); \
         }                                                                                                                       \
         hipLaunchKernelGGL((k_attn<NW_, QT_>), dim3(H, B), dim3(NW_ * 64), lds, st, (const bf16_t *)qkv,                        \
-                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2, row_off, T, g_attn_skew,          \
-                           4 * crh::current_device_cus());                                                                      \
+                           (const unsigned long long *)kmask, (bf16_t *)out, L, H, scale_log2, row_off, T);                     \
     } while (0)
     static int force = -1;   // CODERAG_HIP_ATTN_CFG=<waves> (4, 8, 16; tuning only)
     if (force < 0) {

@@ -48,14 +48,9 @@ __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ (r & 7
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
                                                         const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                        bf16_t *__restrict__ C, int M, int N, int K, int skew)
+                                                        bf16_t *__restrict__ C, int M, int N, int K)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // Every CU walks tiles of equal cost from a common start, so all 256 reach their epilogues -- 128 KB of stores each --
-    // within the same microsecond.  `skew` > 0 starts every other workgroup of an XCD label skew x 1024 cycles late (measured:
-    // tools/skew_sweep.py).
-    if (skew > 0 && ((blockIdx.x >> 3) & 1))
-        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(16);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;

@@ -822,6 +822,116 @@ __device__ KeyT wg_kth_largest(Get get, unsigned int n, unsigned int k, unsigned
     return prefix;
 }
 
+// k-th largest (1-based) of n u32 keys in TWO steps instead of four radix passes.  The keys of one query -- candidate scores
+// above a common threshold, or tile maxima of one query -- sit in a narrow band of the u32 range, so an order-preserving LINEAR
+// bucketing of [lo, hi] into NB buckets (lo / hi: smallest / largest key above `floor_key`, which takes the -inf padding out of
+// the range) isolates the k-th key's bucket with ONE histogram pass; that bucket's members (n / NB on average) are then ranked
+// by counting.  Exact: the bucket function is monotone in the key, and the same function files and retrieves.  When the bucket
+// holds more than CAP keys (masses of equal scores) the radix passes of wg_kth_largest take over.
+// scratch: NB + CAP + 2 * (NT / 64) + 8 words of LDS.  All threads call; the key is returned to every thread.
+template <int NT, int NB, int CAP, typename Get>
+__device__ uint32_t wg_kth_largest_fast(Get get, unsigned int n, unsigned int k, uint32_t floor_key, unsigned int *scratch,
+                                        unsigned int *radix_hist /*(NT/64)*256*/, unsigned int *bcast /*2*/)
+{
+    constexpr int NW = NT / 64;
+    static_assert(NB % 64 == 0 && NB <= NT, "one thread per bucket in the scan");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int *hist = scratch, *list = scratch + NB, *wlo = list + CAP, *whi = wlo + NW, *ctl = whi + NW;   // ctl[0..5]
+    // 1. range of the keys above the floor, and how many sit at or below it
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    unsigned int below = 0u;
+    for (unsigned int i = tid; i < n; i += NT) {
+        const uint32_t key = get(i);
+        if (key > floor_key) {
+            lo = key < lo ? key : lo;
+            hi = key > hi ? key : hi;
+        } else {
+            ++below;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+        below += __shfl_xor(below, d);
+    }
+    for (int i = tid; i < NB; i += NT) hist[i] = 0u;
+    if (tid < 6) ctl[tid] = 0u;
+    __syncthreads();
+    if (lane == 0) {
+        wlo[wave] = lo;
+        whi[wave] = hi;
+        atomicAdd(&ctl[0], below);
+    }
+    __syncthreads();
+    lo = 0xffffffffu;
+    hi = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        lo = wlo[w] < lo ? wlo[w] : lo;
+        hi = whi[w] > hi ? whi[w] : hi;
+    }
+    const unsigned int n_above = n - ctl[0];
+    if (k > n_above) {   // the k-th largest is one of the floor keys: every one of them compares equal for the callers (-inf)
+        return floor_key;
+    }
+    if (lo == hi) return lo;
+    // bucket: monotone non-decreasing in the key (u32 -> f32 conversion, a positive scale and truncation are all monotone)
+    const float scale = (float)NB / ((float)(hi - lo) + 1.0f);
+    auto bucket = [&](uint32_t key) {
+        const unsigned int b = (unsigned int)((float)(key - lo) * scale);
+        return b < (unsigned int)NB ? b : (unsigned int)NB - 1u;
+    };
+    // 2. one histogram pass
+    for (unsigned int i = tid; i < n; i += NT) {
+        const uint32_t key = get(i);
+        if (key > floor_key) atomicAdd(&hist[bucket(key)], 1u);
+    }
+    __syncthreads();
+    // 3. which bucket holds the k-th: thread t owns bucket NB-1-t (descending), suffix sums by wave scan + wave totals
+    unsigned int mine = tid < NB ? hist[NB - 1 - tid] : 0u, incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wlo[wave] = incl;      // (range words are dead: every thread holds lo / hi in registers)
+    __syncthreads();
+    unsigned int before = 0u;
+    for (int w = 0; w < wave; ++w) before += wlo[w];
+    const unsigned int excl = before + incl - mine;
+    if (tid < NB && excl < k && k <= excl + mine) {
+        ctl[1] = (unsigned int)(NB - 1 - tid);   // the bucket
+        ctl[2] = k - excl;                       // rank of the wanted key inside it, from the top
+        ctl[3] = mine;                           // its population
+    }
+    __syncthreads();
+    const unsigned int bsel = ctl[1], rem = ctl[2], pop = ctl[3];
+    if (pop > (unsigned int)CAP) {   // workgroup-uniform: masses of (nearly) equal keys -> the general path
+        __syncthreads();
+        return wg_kth_largest<uint32_t, NT>(get, n, k, radix_hist, bcast);
+    }
+    // 4. the bucket's members, then the rem-th largest of them by counting (equal keys allowed)
+    for (unsigned int i = tid; i < n; i += NT) {
+        const uint32_t key = get(i);
+        if (key > floor_key && bucket(key) == bsel) list[atomicAdd(&ctl[4], 1u)] = key;
+    }
+    __syncthreads();
+    if ((unsigned int)tid < pop) {
+        const uint32_t key = list[tid];
+        unsigned int gt = 0u, ge = 0u;
+        for (unsigned int j = 0; j < pop; ++j) {
+            const uint32_t o = list[j];
+            gt += o > key ? 1u : 0u;
+            ge += o >= key ? 1u : 0u;
+        }
+        if (gt < rem && rem <= ge) ctl[5] = key;   // (every thread holding the wanted VALUE writes the same word)
+    }
+    __syncthreads();
+    return ctl[5];
+}
+
 // descending bitonic sort of P (power of two, <= 2*NT) u64 keys in LDS
 template <int NT>
 __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
@@ -856,6 +966,7 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
     extern __shared__ uint32_t col[];  // [G] ordered keys of this query's tile maxima
     __shared__ unsigned int hist[4 * 256];
     __shared__ unsigned int bcast[2];
+    __shared__ unsigned int fast[256 + 256 + 8 + 8];
     const int q = blockIdx.x;
     float t = -INFINITY;
     if (q >= nq) {   // block-uniform
@@ -863,7 +974,9 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
     } else if (G >= k) {
         for (int i = threadIdx.x; i < G; i += 256) col[i] = ord_f32(gmax[(size_t)i * qstride + q]);
         __syncthreads();
-        const uint32_t key = wg_kth_largest<uint32_t, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k, hist, bcast);
+        // (tile maxima of a filtered or sparse shard may be -inf: they stay out of the bucket range)
+        const uint32_t key = wg_kth_largest_fast<256, 256, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k,
+                                                                ord_f32(-INFINITY), fast, hist, bcast);
         t = unord_f32(key);
         if (t > -INFINITY) t = t - margin;
     }
@@ -926,6 +1039,87 @@ __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf3
     return acc;
 }
 
+// The same two dots with EIGHT lanes per row (lanes 8g .. 8g+7 of a wave; `sub` = lane & 7).  The row is walked in rounds of
+// 8 x 12 pieces (a piece = 8 bf16 of the tiled image / 4 floats of the f32 master): in a round lane `sub` owns 12 consecutive
+// pieces, ALL lanes fetch theirs at once (one memory round trip per round -- a whole 768-wide bf16 row is one round), and the
+// accumulator then travels through the lanes in order: at step j every lane takes lane j-1's running sum and lane j alone adds
+// its elements, one rounded product and one rounded sum at a time; lane 7's sum opens the next round.  The sequence of f32
+// additions is exactly the one of a single thread walking the row (oracle: orc_dot).  The result is valid in lane 7.
+__device__ __forceinline__ float canonical_dot_tiled_x8(const u32x4 *__restrict__ xt, int ksteps, uint32_t row, const float *qv, int sub)
+{
+    const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31);
+    const int npieces = ksteps * 2;              // piece pi = elements 8 pi .. 8 pi + 7: k-step pi >> 1, half pi & 1
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < npieces; r0 += 96) {
+        const int first = r0 + sub * 12;
+        u32x4 pk[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (first + i < npieces) pk[i] = xt[base + (size_t)((first + i) >> 1) * 64 + ((first + i) & 1) * 32];
+        acc = __shfl(acc, 7, 8);                 // the previous round's total (round 0: lane 7 still holds 0)
+        for (int j = 0; j < 8; ++j) {
+            const float prev = __shfl_up(acc, 1, 8);
+            if (sub == j) {
+                if (j > 0) acc = prev;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    if (first + i < npieces) {
+                        asm volatile("" ::: "memory");   // keep the query reads (LDS) next to their use: hoisting all 96 of them spills
+                        const float *qq = qv + (first + i) * 8;
+                        const uint32_t w[4] = {pk[i].x, pk[i].y, pk[i].z, pk[i].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float p0 = qq[2 * e] * bf16_bits_f32(w[e] & 0xffffu);
+                            acc = acc + p0;
+                            float p1 = qq[2 * e + 1] * bf16_bits_f32(w[e] >> 16);
+                            acc = acc + p1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float canonical_dot_f32_x8(const float *__restrict__ xf32, int dim, uint32_t row, const float *qv, int sub)
+{
+    const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
+    const int npieces = dim >> 2;                // piece = one float4
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < npieces; r0 += 96) {
+        const int first = r0 + sub * 12;
+        float4 x[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (first + i < npieces) x[i] = xr[first + i];
+        acc = __shfl(acc, 7, 8);
+        for (int j = 0; j < 8; ++j) {
+            const float prev = __shfl_up(acc, 1, 8);
+            if (sub == j) {
+                if (j > 0) acc = prev;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    if (first + i < npieces) {
+                        asm volatile("" ::: "memory");
+                        const float *qq = qv + 4 * (first + i);
+                        float p;
+                        p = qq[0] * x[i].x;
+                        acc = acc + p;
+                        p = qq[1] * x[i].y;
+                        acc = acc + p;
+                        p = qq[2] * x[i].z;
+                        acc = acc + p;
+                        p = qq[3] * x[i].w;
+                        acc = acc + p;
+                    }
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 // ------------------------------------------------------------------ final selection
 
 // One workgroup per query.  From the query's candidate list (approximate MFMA scores):
@@ -952,6 +1146,7 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     __shared__ unsigned int hist[(NT / 64) * 256];
     __shared__ unsigned int bcast[2];
     __shared__ unsigned int scount;
+    __shared__ unsigned int fast[1024 + 256 + 2 * (NT / 64) + 8];
     const int q = blockIdx.x, tid = threadIdx.x;
     const unsigned int mtrue = qcount[q];
     const unsigned int M = mtrue < (unsigned int)qcap ? mtrue : (unsigned int)qcap;
@@ -984,16 +1179,22 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
         for (unsigned int i = tid; i < M; i += NT) lscore[i] = ord_f32(bits_f32(ql[i].x));
         __syncthreads();
     }
-    const uint32_t akey = staged ? wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return lscore[i]; }, M, kk, hist, bcast)
+    const uint32_t akey = staged ? wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return lscore[i]; }, M, kk, 0u, fast, hist, bcast)
                                  : wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return ord_f32(bits_f32(ql[i].x)); }, M, kk, hist, bcast);
     const float lower = unord_f32(akey) - margin;
     const uint32_t lower_key = ord_f32(lower);
 
-    for (unsigned int i = tid; i < M; i += NT) {
-        const uint32_t sc = staged ? lscore[i] : ord_f32(bits_f32(ql[i].x));
-        if (sc >= lower_key) {
+    for (unsigned int i0 = 0; i0 < M; i0 += NT) {     // (whole waves take part in every round: the compaction uses ballots)
+        const unsigned int i = i0 + tid;
+        const uint32_t sc = i < M ? (staged ? lscore[i] : ord_f32(bits_f32(ql[i].x))) : 0u;
+        const bool keep = i < M && sc >= lower_key;
+        const unsigned long long bm = __ballot(keep);   // one LDS atomic per wave, not one per survivor
+        unsigned int base = 0u;
+        if ((tid & 63) == 0 && bm != 0ull) base = atomicAdd(&scount, (unsigned int)__popcll(bm));
+        base = __shfl(base, 0);
+        if (keep) {
+            const unsigned int p = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bm, 0u));
             const unsigned int row = ql[i].y;
-            const unsigned int p = atomicAdd(&scount, 1u);
             if (p < LCAP) lkeys[p] = (unsigned long long)row;
             sk[p] = (unsigned long long)row;
         }
@@ -1001,14 +1202,22 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     __syncthreads();
     const unsigned int Ms = scount;
     const bool in_lds = Ms <= LCAP;
-    for (unsigned int p = tid; p < Ms; p += NT) {
-        const uint32_t row = (uint32_t)(in_lds ? lkeys[p] : sk[p]);
-        const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv);
-        const unsigned long long key = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
-        if (in_lds)
-            lkeys[p] = key;
-        else
-            sk[p] = key;
+    // Canonical re-score, EIGHT lanes per survivor: lane j of a group fetches its eighth of the row in one batch of independent
+    // loads (one memory round trip for the whole row instead of six) and forms its products; the sum then runs through the
+    // eight lanes in index order, lane j continuing from lane j-1's partial sum -- the same sequence of f32 additions as one
+    // thread walking the row (oracle: orc_dot).
+    for (unsigned int p0 = 0; p0 < Ms; p0 += NT / 8) {
+        const unsigned int p = p0 + (tid >> 3);
+        const bool live = p < Ms;
+        const uint32_t row = live ? (uint32_t)(in_lds ? lkeys[p] : sk[p]) : 0u;
+        const float c = F32 ? canonical_dot_f32_x8(xf32, dim, row, qv, tid & 7) : canonical_dot_tiled_x8(xt, ksteps, row, qv, tid & 7);
+        if (live && (tid & 7) == 7) {      // (the group that read lkeys[p] is the one that overwrites it: program order inside a wave)
+            const unsigned long long key = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+            if (in_lds)
+                lkeys[p] = key;
+            else
+                sk[p] = key;
+        }
     }
     __syncthreads();
     const unsigned int k2 = (unsigned int)k < Ms ? (unsigned int)k : Ms;

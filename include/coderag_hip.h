@@ -315,9 +315,6 @@ int crh_debug_read_ceiling(crh_index *h, void *stream);
 int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
                            int variant, void *stream);
 
-/* Start offsets (units of 1024 cycles; 0 = none) between the attention workgroups sharing a CU / between neighbouring GEMM
- * workgroups: run-time switch for tools/skew_sweep.py; the product library uses the compiled-in defaults. */
-int crh_debug_set_skew(int attn_units, int gemm_units);
 #endif /* CRH_ENABLE_DEBUG */
 
 #ifdef __cplusplus
