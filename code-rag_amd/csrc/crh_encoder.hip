@@ -190,81 +190,82 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t *__restrict__ id
 }
 
 // ------------------------------------------------------------------ row LayerNorm (in place), D = 768
+// (One wave per row, 8-byte accesses.  A form with two rows per wave and 16-byte accesses -- three dwordx4 per lane -- was measured
+// in round 3: O-projection + LayerNorm 134 us against 126, FFN2 + LayerNorm 308 against 305 at 65 k tokens; half as many waves in
+// flight cost more than the wider accesses returned.  Not shipped.)
 
-// One wave normalises TWO rows: 2 x 1536 bytes = 192 pieces of 16 bytes = three dwordx4 accesses per lane (8-byte accesses,
-// one row per wave, reached 5.2-6.0 TB/s: the 16-byte form is what the memory system wants).  Piece c = 64 i + lane (i = 0..2)
-// belongs to row c / 96, columns 8 (c % 96) .. +7: row 0 = {i = 0: all lanes, i = 1: lanes 0-31}, row 1 = the rest.  The two
-// rows' sums are reduced side by side.  RES: the pre-LN sum x + residual is formed here in f32 (x = the GEMM output WITHOUT the
-// residual) -- used where the GEMM's residual epilogue costs more than this kernel's extra read: the O-projection (K = 768), whose
-// epilogue would pull 128 KB of cold residual per CU and tile with the matrix pipe idle (+31 us per call at 65 k tokens against
-// +18 us here).  rows odd: the last wave's second row is masked.
-template <bool RES>
-__global__ __launch_bounds__(256) void k_layernorm768(bf16_t *__restrict__ x, const bf16_t *__restrict__ res, const float *__restrict__ gamma,
+__global__ __launch_bounds__(256) void k_layernorm768(bf16_t *__restrict__ x, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, float eps, int rows)
 {
     const int lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-    if (r0 >= rows) return;
-    const bool two = r0 + 1 < rows;
-    float v[3][8];
-    int col[3];
-    bool second[3], on[3];
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bf16_t *p = x + (size_t)r * 768;
+    float v[12];
+    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int c = 64 * i + lane;
-        second[i] = c >= 96;
-        col[i] = (second[i] ? c - 96 : c) * 8;
-        on[i] = !second[i] || two;
-        u32x4 w = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
-        if (on[i]) {
-            const size_t off = (size_t)(r0 + (second[i] ? 1 : 0)) * 768 + col[i];
-            w = *reinterpret_cast<const u32x4 *>(x + off);
-            if (RES) z = *reinterpret_cast<const u32x4 *>(res + off);
-        }
-        const unsigned int ww[4] = {w.x, w.y, w.z, w.w}, zz[4] = {z.x, z.y, z.z, z.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[i][2 * e] = bf2f(ww[e] & 0xffffu) + (RES ? bf2f(zz[e] & 0xffffu) : 0.f);
-            v[i][2 * e + 1] = bf2f(ww[e] >> 16) + (RES ? bf2f(zz[e] >> 16) : 0.f);
-        }
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p + i * 256 + lane * 4);
+        v[4 * i] = bf2f(w.x & 0xffffu);
+        v[4 * i + 1] = bf2f(w.x >> 16);
+        v[4 * i + 2] = bf2f(w.y & 0xffffu);
+        v[4 * i + 3] = bf2f(w.y >> 16);
+        s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
     }
-    float s0 = 0.f, s1 = 0.f;
+    const float mu = wave_sum(s) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + eps);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float t = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t += v[i][e];
-        if (second[i])
-            s1 += t;
-        else
-            s0 += t;
+        const int e = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        u32x2 o;
+        o.x = pack2((v[4 * i] - mu) * rstd * g.x + b.x, (v[4 * i + 1] - mu) * rstd * g.y + b.y);
+        o.y = pack2((v[4 * i + 2] - mu) * rstd * g.z + b.z, (v[4 * i + 3] - mu) * rstd * g.w + b.w);
+        *reinterpret_cast<u32x2 *>(p + e) = o;
     }
-    const float mu0 = wave_sum(s0) * (1.f / 768.f), mu1 = wave_sum(s1) * (1.f / 768.f);
-    float q0 = 0.f, q1 = 0.f;
+}
+
+// LayerNorm(x + residual): the pre-LN sum is formed here in f32 (x = the GEMM output WITHOUT the residual).  Used where the
+// GEMM's residual epilogue costs more than this kernel's extra read: the O-projection (K = 768), whose epilogue would pull
+// 128 KB of cold residual per CU and tile with the matrix pipe idle (+31 us per call at 65 k tokens against +18 us here).
+__global__ __launch_bounds__(256) void k_layernorm768_res(bf16_t *__restrict__ x, const bf16_t *__restrict__ res, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bf16_t *p = x + (size_t)r * 768;
+    const bf16_t *pr = res + (size_t)r * 768;
+    float v[12];
+    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float mu = second[i] ? mu1 : mu0;
-        float t = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t += (v[i][e] - mu) * (v[i][e] - mu);
-        if (second[i])
-            q1 += t;
-        else
-            q0 += t;
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p + i * 256 + lane * 4);
+        const u32x2 z = *reinterpret_cast<const u32x2 *>(pr + i * 256 + lane * 4);
+        v[4 * i] = bf2f(w.x & 0xffffu) + bf2f(z.x & 0xffffu);
+        v[4 * i + 1] = bf2f(w.x >> 16) + bf2f(z.x >> 16);
+        v[4 * i + 2] = bf2f(w.y & 0xffffu) + bf2f(z.y & 0xffffu);
+        v[4 * i + 3] = bf2f(w.y >> 16) + bf2f(z.y >> 16);
+        s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
     }
-    const float rstd0 = rsqrtf(wave_sum(q0) * (1.f / 768.f) + eps), rstd1 = rsqrtf(wave_sum(q1) * (1.f / 768.f) + eps);
+    const float mu = wave_sum(s) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + eps);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (!on[i]) continue;
-        const float mu = second[i] ? mu1 : mu0, rstd = second[i] ? rstd1 : rstd0;
-        const float4 g0 = *reinterpret_cast<const float4 *>(gamma + col[i]), g1 = *reinterpret_cast<const float4 *>(gamma + col[i] + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(beta + col[i]), b1 = *reinterpret_cast<const float4 *>(beta + col[i] + 4);
-        u32x4 o;
-        o.x = pack2((v[i][0] - mu) * rstd * g0.x + b0.x, (v[i][1] - mu) * rstd * g0.y + b0.y);
-        o.y = pack2((v[i][2] - mu) * rstd * g0.z + b0.z, (v[i][3] - mu) * rstd * g0.w + b0.w);
-        o.z = pack2((v[i][4] - mu) * rstd * g1.x + b1.x, (v[i][5] - mu) * rstd * g1.y + b1.y);
-        o.w = pack2((v[i][6] - mu) * rstd * g1.z + b1.z, (v[i][7] - mu) * rstd * g1.w + b1.w);
-        *reinterpret_cast<u32x4 *>(x + (size_t)(r0 + (second[i] ? 1 : 0)) * 768 + col[i]) = o;
+        const int e = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        u32x2 o;
+        o.x = pack2((v[4 * i] - mu) * rstd * g.x + b.x, (v[4 * i + 1] - mu) * rstd * g.y + b.y);
+        o.y = pack2((v[4 * i + 2] - mu) * rstd * g.z + b.z, (v[4 * i + 3] - mu) * rstd * g.w + b.w);
+        *reinterpret_cast<u32x2 *>(p + e) = o;
     }
 }
 
@@ -1140,9 +1141,9 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
     const int epi = ln_side ? 0 : 2;
     CRH_TRY(launch_tiled(epi, x, w, bias, residual, y, T, N, K, st));
     if (ln_side)
-        hipLaunchKernelGGL(k_layernorm768<true>, dim3((unsigned)ceil_div(T, 8)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
+        hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
     else
-        hipLaunchKernelGGL(k_layernorm768<false>, dim3((unsigned)ceil_div(T, 8)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)nullptr, gamma, beta, eps, T);
+        hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

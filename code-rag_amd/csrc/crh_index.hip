@@ -221,11 +221,11 @@ int build_mask(crh_index *h, crh_index::Workspace &w, const crh_filter *filters,
 // scan kernel instantiations: k-steps = dim / 16; 64 queries per pass except for dim 1536 (32: LDS)
 template <int MODE>
 int launch_scan(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int nitems, int stride, int wave_cap, int qcap,
-                SearchStatus *stt, ScanPrep prep = ScanPrep{nullptr, 0, 0, nullptr, nullptr})
+                SearchStatus *stt)
 {
 #define CRH_SCAN(KS, QB)                                                                                                       \
     hipLaunchKernelGGL((k_scan<KS, MODE, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, w.qfrag, w.tau, \
-                       mask, nitems, stride, w.gmax, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt, prep)
+                       mask, nitems, stride, w.gmax, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt)
     switch (h->ksteps) {
     case 24: CRH_SCAN(24, 2); break;
     case 48: CRH_SCAN(48, 2); break;
@@ -278,27 +278,18 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     const int width = wide ? nblk * 32 : h->batch_q;       // query slots prepared (slots >= nq are zero queries, tau = +inf)
     const int qstride = wide ? kWideQ : 64;                // row pitch of the seed maxima
 
-    // (<= 64 queries: the seed scan prepares the queries itself -- one launch less; the wide scan keeps k_prep_queries)
-#ifdef CRH_NO_FUSED_PREP
-    const bool fused_prep = false;
-#else
-    const bool fused_prep = !wide;
-#endif
-    if (!fused_prep) {
-        if (h->dtype == CRH_DTYPE_BF16)
-            hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
-        else
-            hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
-        CRH_HIP(hipGetLastError());
-    }
+    if (h->dtype == CRH_DTYPE_BF16)
+        hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
+    else
+        hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
+    CRH_HIP(hipGetLastError());
 
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     if (wide)
         CRH_TRY(launch_scan_wide<0>(h, w, st, mask, G, stride, nblk, wave_cap, qcap, stt));
     else
-        CRH_TRY(launch_scan<0>(h, w, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt,
-                               fused_prep ? ScanPrep{q_dev, nq, h->dtype == CRH_DTYPE_BF16 ? 1 : 0, w.qn, w.qfrag} : ScanPrep{nullptr, 0, 0, nullptr, nullptr}));
+        CRH_TRY(launch_scan<0>(h, w, scan_blocks(h, G), st, mask, G, stride, wave_cap, qcap, stt));
     hipLaunchKernelGGL(k_tau, dim3(width), dim3(256), (size_t)G * 4, st, w.gmax, G, k, margin, nq, w.tau, qstride);
     CRH_HIP(hipGetLastError());
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));

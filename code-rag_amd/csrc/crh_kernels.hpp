@@ -394,110 +394,24 @@ __device__ __forceinline__ void nt_wait(u32x4 &dst)
 // per-query threshold is one VGPR per lane and the common case costs 32 v_max + 2 compares a tile.
 // QB = number of 32-query MFMA column blocks per pass: 2 (64 queries) while the query image fits LDS beside the kernel's
 // other needs (dim <= 1024), 1 (32 queries) for dim 1536.
-// What the seed scan needs to prepare the batch's queries itself (MODE 0; q == NULL: the image comes from qfrag as in MODE 1).
-struct ScanPrep {
-    const float *q;   // raw queries [nq][16 KSTEPS] on the device
-    int nq;
-    int round_bf16;   // bf16 store: the canonical query is the bf16-rounded one (what the oracle scores with)
-    float *qn;        // out (written by workgroup 0): canonical queries [32 QB][16 KSTEPS]
-    u32x4 *qfrag;     // out (written by workgroup 0): the B-operand image, for the main scan
-};
-
 template <int KSTEPS, int MODE, int WAVES, int RING, int QB = 2>
 __global__ __launch_bounds__(WAVES * 64) void k_scan(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const float *__restrict__ tau,
     const uint32_t *__restrict__ rowmask, int nitems, int tile_stride, float *__restrict__ gmax,
     u32x4 *__restrict__ wave_lists, int wave_cap, unsigned int *__restrict__ qcount,
-    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status, ScanPrep prep)
+    u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
 {
     static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
-    __shared__ u32x4 qs[QB * KSTEPS * 64 + (MODE == 0 ? 64 : 0)];   // (+1 KiB in the seed scan: the staging image of the raw queries)
+    __shared__ u32x4 qs[QB * KSTEPS * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    if (MODE == 0 && prep.q != nullptr) {
-        // The batch's first kernel prepares the queries too (k_prep_queries was a launch of its own: 16 us + a kernel boundary for
-        // 200 KB of work).  EVERY workgroup builds the image straight into its LDS -- Qdrant's cosine_preprocess per query, the
-        // squared length summed sequentially in index order (product and sum rounded separately: oracle orc_cosine_preprocess),
-        // one lane per query; then division, bf16 rounding and the MFMA B-operand layout by all threads -- and workgroup 0 also
-        // writes what the later kernels read: the image (main scan), the canonical queries (k_select) and a zeroed status slot.
-        constexpr int DIM = KSTEPS * 16, CH = DIM / 8, NQS = QB * 32;
-        constexpr int PART = DIM / 2, RS = PART + 4;   // the raw queries pass through LDS half a row at a time, rows padded by 16 bytes
-        static_assert(MODE != 0 || (size_t)NQS * RS * 4 <= sizeof(qs), "staging image of the raw queries");
-        __shared__ float dv_s[NQS];
-        if (blockIdx.x == 0) {
-            uint32_t *w = reinterpret_cast<uint32_t *>(status);
-            for (int i = tid; i < (int)(sizeof(SearchStatus) / 4); i += WAVES * 64) w[i] = 0u;
-        }
-        // squared lengths: lane q of wave 0 walks query q in index order.  Read straight from global memory that walk is a chain
-        // of dependent cache misses (measured: +23 us on the seed scan); so all threads stage the queries into LDS with coalesced
-        // loads -- half a row of every query at a time, which is what fits -- and the 64 running sums continue across the halves.
-        float *stage = reinterpret_cast<float *>(qs);
-        float acc = 0.0f;
-        for (int part = 0; part < 2; ++part) {
-            for (int f = tid; f < NQS * (PART / 4); f += WAVES * 64) {
-                const int qi = f / (PART / 4), c = f - qi * (PART / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (qi < prep.nq) v = reinterpret_cast<const float4 *>(prep.q + (size_t)qi * DIM + part * PART)[c];
-                *reinterpret_cast<float4 *>(stage + qi * RS + 4 * c) = v;
-            }
-            __syncthreads();
-            if (tid < NQS) {
-                const float4 *src = reinterpret_cast<const float4 *>(stage + tid * RS);
-#pragma unroll 8
-                for (int c = 0; c < PART / 4; ++c) {
-                    const float4 v = src[c];
-                    float p;
-                    p = v.x * v.x;
-                    acc = acc + p;
-                    p = v.y * v.y;
-                    acc = acc + p;
-                    p = v.z * v.z;
-                    acc = acc + p;
-                    p = v.w * v.w;
-                    acc = acc + p;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid < NQS) dv_s[tid] = tid < prep.nq ? cosine_divisor(acc) : 0.0f;
-        __syncthreads();
-        for (int item = tid; item < NQS * CH; item += WAVES * 64) {
-            const int qi = item / CH, c8 = item - qi * CH;
-            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (qi < prep.nq) {
-                const float4 *sp = reinterpret_cast<const float4 *>(prep.q + (size_t)qi * DIM + c8 * 8);
-                const float4 a = sp[0], b = sp[1];
-                x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
-            }
-            const float dv = dv_s[qi];
-            uint32_t hb[8];
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xn = dv != 0.0f ? __fdiv_rn(x[j], dv) : x[j];
-                hb[j] = f32_to_bf16_bits(xn);
-                v[j] = prep.round_bf16 ? bf16_bits_f32(hb[j]) : xn;
-            }
-            u32x4 pk;
-            pk.x = hb[0] | (hb[1] << 16);
-            pk.y = hb[2] | (hb[3] << 16);
-            pk.z = hb[4] | (hb[5] << 16);
-            pk.w = hb[6] | (hb[7] << 16);
-            const int slot = ((qi >> 5) * KSTEPS + (c8 >> 1)) * 64 + ((c8 & 1) * 32 + (qi & 31));
-            qs[slot] = pk;
-            if (blockIdx.x == 0) {
-                prep.qfrag[slot] = pk;
-                float4 *dst = reinterpret_cast<float4 *>(prep.qn + (size_t)qi * DIM + c8 * 8);
-                dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-                dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-            }
-        }
-    } else {
-        for (int i = tid; i < QB * KSTEPS * 64; i += WAVES * 64) qs[i] = qfrag[i];
-    }
+    // (Preparing the queries HERE, in the seed scan -- every workgroup building the image in its own LDS, workgroup 0 writing it
+    // out for the later kernels -- was built and measured in round 3: it removes k_prep_queries' launch and adds the same time to
+    // this kernel, 119.7 us against 119.3 us around the main scan.  Not shipped.)
+    for (int i = tid; i < QB * KSTEPS * 64; i += WAVES * 64) qs[i] = qfrag[i];
     float t0 = 0.f, t1 = 0.f;
     if (MODE == 1) {
         t0 = tau[lane & 31];
