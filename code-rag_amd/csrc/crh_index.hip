@@ -48,6 +48,7 @@ struct crh_index {
     int dim = 0, ksteps = 0, dtype = 0, ncols = 0, device = 0, cu_count = 0;
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
+    bool fused_scan = true;   // <= batch_q queries: seed scan + threshold + main scan in one launch (CODERAG_HIP_FUSED_SCAN=0: three)
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -238,6 +239,24 @@ int launch_scan(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t s
     return CRH_OK;
 }
 
+// seed scan + threshold + main scan in one launch (k_scan_fused): <= batch_q queries, the default sample size
+int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int ntiles, int G, int S, int k, float margin,
+                      int nq, int wave_cap, int qcap, SearchStatus *stt)
+{
+#define CRH_FUSED(KS, QB)                                                                                                          \
+    hipLaunchKernelGGL((k_scan_fused<KS, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, w.qfrag, mask, ntiles, G, S, \
+                       w.gmax, w.tau, k, margin, nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt)
+    switch (h->ksteps) {
+    case 24: CRH_FUSED(24, 2); break;
+    case 48: CRH_FUSED(48, 2); break;
+    case 96: CRH_FUSED(96, 1); break;
+    default: return fail(CRH_E_INTERNAL, "no fused scan kernel for %d k-steps", h->ksteps);   // (dim 1024: its 128 KB query image leaves no LDS for the threshold step)
+    }
+#undef CRH_FUSED
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 // the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
 template <int MODE>
 int launch_scan_wide(crh_index *h, crh_index::Workspace &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
@@ -284,6 +303,30 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
     CRH_HIP(hipGetLastError());
 
+    // <= batch_q queries at the default sample size: seed scan, threshold and main scan are ONE launch (k_scan_fused: every wave's
+    // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
+    // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
+    if (!wide && h->fused_scan && h->seed_tiles == 4096 && h->ksteps != 64) {
+        const int blocks = scan_blocks(h, ntiles);
+        const int waves = blocks * kWaves;
+        const int Gf = (int)std::min<int64_t>(std::min(waves, 4096), ntiles);
+        const int Sf = Gf == waves ? (int)std::max<int64_t>(1, ntiles / Gf) : 1;
+        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
+        CRH_TRY(launch_scan_fused(h, w, blocks, st, mask, (int)ntiles, Gf, Sf, k, margin, nq, wave_cap, qcap, stt));
+        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
+        if (h->dtype == CRH_DTYPE_F32)
+            hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+        else
+            hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+        CRH_HIP(hipGetLastError());
+        h->stats.rows += h->count;
+        h->stats.tiles += ntiles;
+        h->stats.seed_tiles += Gf;
+        h->stats.batches += 1;
+        return CRH_OK;
+    }
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     if (wide)
@@ -339,6 +382,8 @@ int finish_pending(crh_index *h, hipStream_t st)
                 h->prof_scan_launches += 1;
             }
         }
+        if (s.bar_timeout)
+            return fail(CRH_E_INTERNAL, "a grid-wide wait of the fused scan timed out (a workgroup never became resident): the results of this batch are void");
         int attempts = 0;
         while (s.wave_overflow || s.q_overflow) {
             if (++attempts > 4) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
@@ -414,6 +459,10 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     h->ksteps = dim / 16;
     h->batch_q = dim > 1024 ? 32 : 64;   // (k_scan's 64-query image does not fit LDS at dim 1536)
     h->wide_ok = dim <= 768 && getenv("CODERAG_HIP_NO_WIDE_SCAN") == nullptr;   // (the env switch exists for A/B timing only)
+    {
+        const char *e = getenv("CODERAG_HIP_FUSED_SCAN");
+        h->fused_scan = !(e && e[0] == '0');
+    }
     h->dtype = dtype;
     h->ncols = n_code_cols;
     h->device = device;

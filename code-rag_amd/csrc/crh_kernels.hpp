@@ -39,7 +39,9 @@ struct SearchStatus {
     unsigned int wave_overflow;
     unsigned int q_overflow;
     unsigned long long candidates;
-    unsigned long long pad_;
+    unsigned int bar_a, bar_b;   // arrival counters of the two grid-wide waits of k_scan_fused (zeroed with the slot)
+    unsigned int bar_timeout;    // set when one of those waits gave up (a workgroup never became resident): results are void
+    unsigned int pad_;
     unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
 };
 
@@ -320,7 +322,7 @@ template <bool ROUND_BF16>
 __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q, int nq, int dim, int ksteps,
                                                      float *__restrict__ qn, u32x4 *__restrict__ qfrag, SearchStatus *__restrict__ status)
 {
-    __shared__ float qs[2048];
+    __shared__ __attribute__((aligned(16))) float qs[2048];
     __shared__ float dv_s;
     const int qi = blockIdx.x, tid = threadIdx.x;
     if (qi == 0) {   // the batch's status slot starts from zero (first kernel of the batch: saves a memset node per search)
@@ -333,10 +335,18 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q
     __syncthreads();
     if (tid == 0) {
         float acc = 0.0f;  // index order, product and sum rounded separately (oracle: orc_cosine_preprocess)
-#pragma unroll 8
-        for (int i = 0; i < dim; ++i) {
-            float v = qs[i];
-            float p = v * v;
+        const float4 *q4 = reinterpret_cast<const float4 *>(qs);   // 16-byte LDS reads, four deep: the chain of additions is what is left
+#pragma unroll 4
+        for (int i = 0; i < (dim >> 2); ++i) {
+            const float4 v = q4[i];
+            float p;
+            p = v.x * v.x;
+            acc = acc + p;
+            p = v.y * v.y;
+            acc = acc + p;
+            p = v.z * v.z;
+            acc = acc + p;
+            p = v.w * v.w;
             acc = acc + p;
         }
         dv_s = cosine_divisor(acc);
@@ -956,6 +966,252 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
         }
     }
     __syncthreads();
+}
+
+// ------------------------------------------------------------------ seed scan + threshold + main scan in ONE launch
+
+// One of the two grid-wide waits of k_scan_fused: every storing wave drains its stores, the workgroup meets, ONE lane publishes
+// (agent-scope release, then the arrival) and polls the counter with relaxed loads until `expected` arrivals are in, acquires
+// (agent scope: this CU's L1 is invalidated) and the workgroup meets again -- the placement-independent protocol of the CDNA
+// guide (Guideline 16, counter form).  The spin is bounded: a workgroup that never becomes resident ends the wait with
+// status->bar_timeout set, which the host reports as an error instead of hanging.
+__device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int expected, bool arrive, SearchStatus *status)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (arrive) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the fence's own wait can be dropped by the compiler: keep this one)
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned int spins = 0u;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) {
+                __hip_atomic_store(&status->bar_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// The <= 64-query batch in three launches instead of five: k_prep_queries, THIS, k_select.  The seed scan, the threshold and the
+// main scan used to be separate kernels; the sample tiles (201 MB at 10M rows) were read twice and two kernel boundaries sat on
+// the critical path.  Here every wave's FIRST tile is its sample tile -- wave g of the grid takes tile g * S, a strided sample
+// of G tiles (G = waves in the grid, 4096 on 256 CUs) -- and its accumulators stay in registers while
+//   1. the tile maxima go to gmax[q][g], grid-wide wait A (everybody's maxima are visible);
+//   2. workgroup q computes tau[q] = the k-th largest of query q's G maxima minus the margin (wg_kth_largest_fast: 1024 threads,
+//      ~2 us), grid-wide wait B (arrivals: the tau workgroups only; everybody waits);
+//   3. every wave filters its retained sample tile against tau and walks on through the tiles that are not samples, in the
+//      interleaved order of k_scan (remaining tile r = wave + j * waves), with the same ring of loads and the same per-tile work.
+// The corpus is read exactly once per batch.  Requires the whole grid resident (one workgroup per CU: the LDS footprint pins
+// that, the grid is never larger than the CU count); the waits are bounded (grid_wait).  Thresholds, candidate compaction and
+// the hand-over to the per-query lists are k_scan's.
+template <int KSTEPS, int WAVES, int RING, int QB = 2>
+__global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
+    const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
+    float *__restrict__ gmax, float *__restrict__ tau_g, int k, float margin, int nq, u32x4 *__restrict__ wave_lists, int wave_cap,
+    unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
+{
+    static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
+    constexpr int NT = WAVES * 64, NQS = QB * 32;
+    __shared__ u32x4 qs[QB * KSTEPS * 64];
+    __shared__ uint32_t col[4096];                       // one query's tile maxima as ordered keys (G <= 4096)
+    __shared__ unsigned int hist[(NT / 64) * 256];
+    __shared__ unsigned int bcast[2];
+    __shared__ unsigned int fast[1024 + 256 + 2 * (NT / 64) + 8];
+    __shared__ float tau_s[NQS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+
+    for (int i = tid; i < QB * KSTEPS * 64; i += NT) qs[i] = qfrag[i];
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    const int gw = blockIdx.x * WAVES + wave;
+    u32x4 *mylist = wave_lists + (size_t)gw * wave_cap;
+    unsigned int wcnt = 0;
+
+    // the tiles that are not samples, r = 0 .. nrem-1 in ascending tile order: below G * S every S-th tile is a sample
+    const int nrem = ntiles - G, GS1 = G * (S - 1), Sm1 = S > 1 ? S - 1 : 1;
+    auto tile_of = [&](int r) -> int64_t { return r < GS1 ? (int64_t)r + r / Sm1 + 1 : (int64_t)r + G; };
+    auto tile_ptr = [&](int64_t tile) { return xt + (size_t)tile * (KSTEPS * 64) + lane; };
+
+    // One tile: KSTEPS x (wait for the oldest of the RING loads in flight, two MFMAs, refill the slot RING steps ahead -- past the
+    // tile's end from the NEXT tile `xn`, so the stream never stops at a tile boundary).  k_scan's inner loop.
+    u32x4 ring[RING];
+    auto scan_tile = [&](const u32x4 *xp, const u32x4 *xn, f32x16 &c0, f32x16 &c1) {
+        asm volatile("" ::: "memory");         // (keeps the query image out of the loop-invariant registers: see k_scan)
+        u32x4 b0 = qs[lane], b1 = qs[(QB - 1) * KSTEPS * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int s1 = (s + 1 < KSTEPS) ? s + 1 : s;
+            const u32x4 nb0 = qs[s1 * 64 + lane];
+            const u32x4 nb1 = qs[((QB - 1) * KSTEPS + s1) * 64 + lane];
+            nt_wait<RING - 1>(ring[s % RING]);
+            const bf16x8 xa = __builtin_bit_cast(bf16x8, ring[s % RING]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), c0, 0, 0, 0);
+            if (QB == 2) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), c1, 0, 0, 0);
+            const int sp = s + RING;
+            const u32x4 *src = (sp < KSTEPS) ? xp + sp * 64 : xn + (sp - KSTEPS) * 64;
+            nt_load(ring[s % RING], src);
+            b0 = nb0;
+            b1 = nb1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- 1. the sample tile of this wave; its loads already run ahead into the wave's first ordinary tile, whose first pieces
+    // then sit in registers while the thresholds are worked out
+    f32x16 a0 = {0}, a1 = {0};
+    const bool has_sample = gw < G;
+    const int64_t stile = has_sample ? (int64_t)gw * S : 0;
+    int i = gw;                                                  // index of this wave's next ordinary tile
+    const u32x4 *xp = tile_ptr(i < nrem ? tile_of(i) : 0);       // ... and its address
+    if (has_sample) {
+        const u32x4 *xs = tile_ptr(stile);
+#pragma unroll
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xs + d * 64);
+        scan_tile(xs, xp, a0, a1);
+        const uint32_t vmask = rowmask[stile];
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = (vmask >> row) & 1u;
+            m0 = fmaxf(m0, ok ? a0[r] : -INFINITY);
+            m1 = fmaxf(m1, ok ? a1[r] : -INFINITY);
+        }
+        m0 = fmaxf(m0, __shfl_xor(m0, 32));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        if (h == 0) {
+            gmax[(size_t)lane * G + gw] = m0;                       // [query][sample]: the threshold workgroup reads a row
+            if (QB == 2) gmax[(size_t)(32 + lane) * G + gw] = m1;
+        }
+    } else if (i < nrem) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
+    }
+    grid_wait(&status->bar_a, gridDim.x, true, status);
+
+    // ---- 2. thresholds: workgroup q (and q + gridDim.x, ...) owns query q
+    for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
+        float t = -INFINITY;
+        if (q >= nq) {                 // padding column of a short batch: nominates nothing
+            t = INFINITY;
+        } else if (G >= k) {
+            for (int i = tid; i < G; i += NT) col[i] = ord_f32(gmax[(size_t)q * G + i]);
+            __syncthreads();
+            const uint32_t key = wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k,
+                                                                    ord_f32(-INFINITY), fast, hist, bcast);
+            t = unord_f32(key);
+            if (t > -INFINITY) t = t - margin;
+            __syncthreads();
+        }
+        if (tid == 0) tau_g[q] = t;
+    }
+    const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
+    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    if (tid < NQS) tau_s[tid] = tau_g[tid];
+    __syncthreads();
+    const float t0 = tau_s[lane & 31], t1 = QB == 2 ? tau_s[32 + (lane & 31)] : INFINITY;
+
+    // ---- 3. filter: rows of a tile whose score reaches the query's threshold become candidates (k_scan MODE 1)
+    auto emit = [&](int64_t tile, const f32x16 &c0, const f32x16 &c1, uint32_t vmask) {
+        float m0 = c0[0], m1 = c1[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            m0 = fmaxf(m0, c0[r]);
+            m1 = fmaxf(m1, c1[r]);
+        }
+        const bool any = (m0 >= t0) || (m1 >= t1);
+        if (__ballot(any) != 0ull && vmask != 0u) {
+            const uint32_t rowbase = (uint32_t)(tile * 32);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float tq = qb ? t1 : t0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float sc = qb ? c1[r] : c0[r];
+                    const bool pass = ((vmask >> row) & 1u) && (sc >= tq);
+                    const unsigned long long pm = __ballot(pass);
+                    if (pm != 0ull) {
+                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                        const unsigned int pos = wcnt + pre;
+                        if (pass && pos < (unsigned int)wave_cap) {
+                            u32x4 e;
+                            e.x = f32_bits(sc);
+                            e.y = rowbase + row;
+                            e.z = (uint32_t)(qb * 32 + (lane & 31));
+                            e.w = 0u;
+                            mylist[pos] = e;
+                        }
+                        wcnt += (unsigned int)__popcll(pm);
+                    }
+                }
+            }
+        }
+    };
+    if (has_sample) emit(stile, a0, a1, rowmask[stile]);
+
+    while (i < nrem) {
+        const int inext = i + total;
+        const int64_t tile = tile_of(i);
+        const u32x4 *xn = (inext < nrem) ? tile_ptr(tile_of(inext)) : xp;
+        const uint32_t vmask = rowmask[tile];  // wave-uniform -> scalar load
+        f32x16 c0 = {0}, c1 = {0};
+        scan_tile(xp, xn, c0, c1);
+        emit(tile, c0, c1, vmask);
+        xp = xn;
+        i = inext;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the last tile are still in flight
+
+    // ---- hand the workgroup's candidates over to the per-query lists (as k_scan does)
+    __syncthreads();
+    unsigned int *wc = reinterpret_cast<unsigned int *>(qs);  // [WAVES] counts, [64] hist, [64] base, [64] off
+    unsigned int *qh = wc + WAVES;
+    unsigned int *base = qh + 64;
+    unsigned int *off = base + 64;
+    if (lane == 0) {
+        wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+        atomicMax(&status->max_wave_cnt, wcnt);
+        if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
+    }
+    if (tid < 64) {
+        qh[tid] = 0u;
+        off[tid] = 0u;
+    }
+    __syncthreads();
+    const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
+    for (int w = 0; w < WAVES; ++w) {
+        const unsigned int n = wc[w];
+        for (unsigned int e = tid; e < n; e += NT) atomicAdd(&qh[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) base[tid] = qh[tid] ? atomicAdd(&qcount[tid], qh[tid]) : 0u;
+    __syncthreads();
+    for (int w = 0; w < WAVES; ++w) {
+        const unsigned int n = wc[w];
+        for (unsigned int e = tid; e < n; e += NT) {
+            const u32x4 c = wl[(size_t)w * wave_cap + e];
+            const unsigned int q = c.z & 63u;
+            const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+            if (idx < (unsigned int)qcap) {
+                u32x2 o;
+                o.x = c.x;
+                o.y = c.y;
+                qlist[(size_t)q * qcap + idx] = o;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ threshold from the seed sample

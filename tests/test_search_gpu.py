@@ -485,3 +485,47 @@ def test_wide_scan_equals_the_64_query_passes_and_survives_overflow(gpu, monkeyp
     assert np.array_equal(fr, wr) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
     wide.close()
     narrow.close()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("dim,n", [(768, 5), (768, 131072), (768, 131073 + 32 * 7), (768, 400_000), (384, 300_000), (1536, 150_000)])
+def test_fused_scan_equals_the_three_kernel_form_and_the_oracle(gpu, monkeypatch, dim, n, bf16):
+    """k_scan_fused (every wave's first tile is its sample tile, two grid-wide waits, one corpus pass -- the default for <= 64
+    queries) against the seed scan / threshold / main scan as three launches (CODERAG_HIP_FUSED_SCAN=0) and against the oracle:
+    fewer tiles than waves (every tile a sample), exactly as many, a ragged tail beyond G * S, several tiles per wave; filters,
+    tombstones, short batches, k beyond the row count, consecutive calls with different queries (thresholds of the previous
+    call must not leak), and the regrow path."""
+    ffi = _ffi()
+    rng = np.random.default_rng(n + dim)
+    x = rng.standard_normal((n, dim), dtype=np.float32)
+    codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
+    dead = rng.choice(n, n // 20, replace=False)
+    dt = ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32
+    fused = ffi.Index(dim, dt, capacity_rows=n, n_code_cols=1)
+    monkeypatch.setenv("CODERAG_HIP_FUSED_SCAN", "0")
+    three = ffi.Index(dim, dt, capacity_rows=n, n_code_cols=1)
+    monkeypatch.delenv("CODERAG_HIP_FUSED_SCAN")
+    for idx in (fused, three):
+        idx.append(x, codes)
+        idx.tombstone(dead)
+    alive = np.ones(n, np.uint8)
+    alive[dead] = 0
+    nqmax = 32 if dim == 1536 else 64
+    for it, (nq, k, flt) in enumerate(((nqmax, 100, None), (3, 10, [(0, 1)]), (1, 1000, None), (nqmax, 7, [(0, 2)]), (17, 100, None))):
+        q = rng.standard_normal((nq, dim), dtype=np.float32)
+        if it == 0 and n > 10:
+            q[0] = x[n // 2]                                    # an exact hit
+        fs, fr = fused.search(q, k, filters=flt)
+        ts, tr = three.search(q, k, filters=flt)
+        assert np.array_equal(fr, tr) and np.array_equal(fs.view(np.uint32), ts.view(np.uint32)), (it, nq, k)
+        assert fused.stats()["fallback_used"] == 0 or n < 64
+        if n <= 200_000:
+            es, er = orc.cosine_search(x, q, k, bf16=bf16, alive=alive, codes=codes, filters=flt or [])
+            assert np.array_equal(fr, er) and np.array_equal(fs.view(np.uint32), es.view(np.uint32)), (it, nq, k)
+    fused.set_tuning(force_fallback=1)
+    q = rng.standard_normal((9, dim), dtype=np.float32)
+    fs, fr = fused.search(q, 50)
+    ts, tr = three.search(q, 50)
+    assert fused.stats()["fallback_used"] == 1 and np.array_equal(fr, tr) and np.array_equal(fs.view(np.uint32), ts.view(np.uint32))
+    fused.close()
+    three.close()
