@@ -245,7 +245,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 {
 #define CRH_FUSED(KS, QB)                                                                                                          \
     hipLaunchKernelGGL((k_scan_fused<KS, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, w.qfrag, mask, ntiles, G, S, \
-                       w.gmax, w.tau, k, margin, nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt)
+                       w.gmax, w.tau, k, margin, nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt, h->force_fallback == 2 ? 1 : 0)
     switch (h->ksteps) {
     case 24: CRH_FUSED(24, 2); break;
     case 48: CRH_FUSED(48, 2); break;
@@ -382,14 +382,21 @@ int finish_pending(crh_index *h, hipStream_t st)
                 h->prof_scan_launches += 1;
             }
         }
-        if (s.bar_timeout)
-            return fail(CRH_E_INTERNAL, "a grid-wide wait of the fused scan timed out (a workgroup never became resident): the results of this batch are void");
         int attempts = 0;
-        while (s.wave_overflow || s.q_overflow) {
-            if (++attempts > 4) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
-            h->stats.fallback_used = 1;
-            const int wc = std::max(w.ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
-            const int qc = std::max(w.ws_qcap, next_pow2((int64_t)s.max_qcount));
+        while (s.bar_timeout || s.wave_overflow || s.q_overflow) {
+            if (++attempts > 5) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
+            if (s.bar_timeout) {
+                // A grid-wide wait of the fused scan gave up: some workgroup was not resident for ~1 s (other streams' kernels
+                // holding CUs).  The batch's results are void; this index goes back to the three-launch form, which needs no
+                // co-residency, and the batch is run again.
+                h->fused_scan = false;
+                h->stats.fallback_used |= 2;
+            } else {
+                h->stats.fallback_used |= 1;
+            }
+            // (the counts of a timed-out batch mean nothing: its thresholds were never agreed on -- the buffers stay as they are)
+            const int wc = s.bar_timeout ? w.ws_wave_cap : std::max(w.ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
+            const int qc = s.bar_timeout ? w.ws_qcap : std::max(w.ws_qcap, next_pow2((int64_t)s.max_qcount));
             CRH_TRY(ensure_workspace(h, w, wc, qc));
             const uint32_t *mask = nullptr;
             CRH_TRY(build_mask(h, w, p.filt, p.nfilt, &mask, st));
@@ -892,6 +899,15 @@ int crh_debug_read_ceiling(crh_index *h, void *stream)
 }
 #endif  // CRH_ENABLE_DEBUG
 
+#ifdef CRH_FUSED_STAMPS   // a measurement build only (tools/fused_stamps.py): per-workgroup phase clocks of the last k_scan_fused
+int crh_debug_fused_stamps(unsigned long long *out)
+{
+    CRH_HIP(hipDeviceSynchronize());
+    CRH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 256 * 24));
+    return CRH_OK;
+}
+#endif
+
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
 {
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
@@ -915,9 +931,10 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    // force_fallback (testing): start from absurdly small candidate buffers so the regrow-and-rerun path runs
-    const int wc = h->force_fallback ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
-    const int qc = h->force_fallback ? 8 : std::max(h->qcap, h->ws.ws_qcap);
+    // force_fallback (testing): 1 = start from absurdly small candidate buffers so the regrow-and-rerun path runs;
+    // 2 = the one-launch scan's first grid-wide wait expects an arrival too many, so its time-out path runs
+    const int wc = h->force_fallback == 1 ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
+    const int qc = h->force_fallback == 1 ? 8 : std::max(h->qcap, h->ws.ws_qcap);
     CRH_TRY(ensure_workspace(h, h->ws, wc, qc));
 
     const float *q_dev = queries;

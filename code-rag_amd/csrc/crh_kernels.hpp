@@ -973,8 +973,10 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
 // One of the two grid-wide waits of k_scan_fused: every storing wave drains its stores, the workgroup meets, ONE lane publishes
 // (agent-scope release, then the arrival) and polls the counter with relaxed loads until `expected` arrivals are in, acquires
 // (agent scope: this CU's L1 is invalidated) and the workgroup meets again -- the placement-independent protocol of the CDNA
-// guide (Guideline 16, counter form).  The spin is bounded: a workgroup that never becomes resident ends the wait with
-// status->bar_timeout set, which the host reports as an error instead of hanging.
+// guide (Guideline 16, counter form).  The spin is bounded in TIME (0.5 s): a workgroup that does not become resident (another
+// stream's kernel holding its CU) ends the wait with status->bar_timeout set; the host then voids the batch, puts the index
+// back on the three-launch form and runs the batch again (finish_pending).
+constexpr unsigned long long kGridWaitTicks = 50000000ull;
 __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int expected, bool arrive, SearchStatus *status)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -985,10 +987,11 @@ __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int ex
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the fence's own wait can be dropped by the compiler: keep this one)
             __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        const unsigned long long t0 = wall_clock64();          // constant 100 MHz
         unsigned int spins = 0u;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 24)) {
+            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > kGridWaitTicks) {
                 __hip_atomic_store(&status->bar_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -1011,12 +1014,24 @@ __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int ex
 // The corpus is read exactly once per batch.  Requires the whole grid resident (one workgroup per CU: the LDS footprint pins
 // that, the grid is never larger than the CU count); the waits are bounded (grid_wait).  Thresholds, candidate compaction and
 // the hand-over to the per-query lists are k_scan's.
+// Phase clocks of a MEASUREMENT build (-DCRH_FUSED_STAMPS, tools/fused_stamps.py); in the product CRH_STAMP is nothing.
+#ifdef CRH_FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[256 * 8 + 256 * 16];
+#define CRH_STAMP(n)                                                                                      \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_fused_stamps[blockIdx.x * 8 + (n)] = wall_clock64();  \
+    } while (0)
+#else
+#define CRH_STAMP(n) ((void)0)
+#endif
+
 template <int KSTEPS, int WAVES, int RING, int QB = 2>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
     float *__restrict__ gmax, float *__restrict__ tau_g, int k, float margin, int nq, u32x4 *__restrict__ wave_lists, int wave_cap,
-    unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status)
+    unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status, int wait_extra)
 {
+    // (wait_extra: 0; a test passes 1 -- wait A then expects an arrival that never comes, which exercises the time-out path)
     static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
     constexpr int NT = WAVES * 64, NQS = QB * 32;
     __shared__ u32x4 qs[QB * KSTEPS * 64];
@@ -1030,8 +1045,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
+    CRH_STAMP(0);
     for (int i = tid; i < QB * KSTEPS * 64; i += NT) qs[i] = qfrag[i];
     __syncthreads();
+    CRH_STAMP(1);
 
     const int total = gridDim.x * WAVES;
     const int gw = blockIdx.x * WAVES + wave;
@@ -1098,7 +1115,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
 #pragma unroll
         for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
     }
-    grid_wait(&status->bar_a, gridDim.x, true, status);
+    CRH_STAMP(2);
+    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
+    CRH_STAMP(3);
 
     // ---- 2. thresholds: workgroup q (and q + gridDim.x, ...) owns query q
     for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
@@ -1117,7 +1136,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
         if (tid == 0) tau_g[q] = t;
     }
     const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
+    CRH_STAMP(4);
     grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
     __syncthreads();
     const float t0 = tau_s[lane & 31], t1 = QB == 2 ? tau_s[32 + (lane & 31)] : INFINITY;
@@ -1173,6 +1194,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
         i = inext;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the last tile are still in flight
+    CRH_STAMP(6);
+#ifdef CRH_FUSED_STAMPS
+    if (lane == 0 && blockIdx.x < 256 && wave < 16) g_fused_stamps[256 * 8 + blockIdx.x * 16 + wave] = wall_clock64();
+#endif
 
     // ---- hand the workgroup's candidates over to the per-query lists (as k_scan does)
     __syncthreads();

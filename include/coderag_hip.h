@@ -62,7 +62,8 @@ typedef struct crh_search_stats {
     int64_t seed_tiles;      /* tiles in the threshold-seeding sample */
     int64_t candidates;      /* (score,row) pairs that passed the scan threshold, all queries */
     int64_t max_query_cands; /* largest per-query candidate count */
-    int32_t fallback_used;   /* 1 if the exact chunked fallback ran */
+    int32_t fallback_used;   /* bit 0: a batch was re-run with larger candidate buffers; bit 1: a grid-wide wait of the
+                                one-launch scan timed out and the index went back to the three-launch form */
     int32_t batches;         /* 64-query batches processed */
 } crh_search_stats;
 
@@ -175,7 +176,8 @@ int crh_index_set_profiling(crh_index *h, int enable);
 int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_launches);
 
 /* Tuning knobs (0 / negative = keep default): seed sample tiles, per-wave candidate
- * capacity, per-query candidate capacity, force the exact chunked fallback (testing). */
+ * capacity, per-query candidate capacity, force_fallback (testing): 1 = start from tiny candidate buffers so the
+ * regrow-and-rerun path runs, 2 = make the one-launch scan's grid-wide wait time out so its recovery path runs, 0 = off. */
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
 

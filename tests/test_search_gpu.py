@@ -529,3 +529,27 @@ def test_fused_scan_equals_the_three_kernel_form_and_the_oracle(gpu, monkeypatch
     assert fused.stats()["fallback_used"] == 1 and np.array_equal(fr, tr) and np.array_equal(fs.view(np.uint32), ts.view(np.uint32))
     fused.close()
     three.close()
+
+
+def test_fused_scan_that_times_out_is_run_again_in_the_three_kernel_form(gpu):
+    """The one-launch scan needs every workgroup resident at its grid-wide waits.  When one is not (another stream's kernels on
+    its CU) the wait gives up after 0.5 s, the batch is void, and the host runs it again with the three-launch form and keeps the
+    index on it.  Provoked here through the tuning hook (wait A expects an arrival too many)."""
+    ffi = _ffi()
+    rng = np.random.default_rng(5)
+    n = 30_000
+    x = rng.standard_normal((n, 768), dtype=np.float32)
+    q = rng.standard_normal((20, 768), dtype=np.float32)
+    es, er = orc.cosine_search(x, q, 25, bf16=True)
+    idx = ffi.Index(768, ffi.DTYPE_BF16, capacity_rows=n)
+    idx.append(x)
+    s, r = idx.search(q, 25)
+    assert idx.stats()["fallback_used"] == 0 and np.array_equal(r, er)
+    idx.set_tuning(force_fallback=2)
+    s, r = idx.search(q, 25)                                   # ~0.5 s: every workgroup sits out the bound
+    assert idx.stats()["fallback_used"] == 2
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    s, r = idx.search(q, 25)                                   # the index stays on the three-launch form: no wait to time out
+    assert idx.stats()["fallback_used"] == 0
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    idx.close()
