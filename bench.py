@@ -297,8 +297,19 @@ def timed_search(torch, idx, qd, K, filters, steps, warmup, stream):
             "scan_launches": launches, "stats": idx.stats(), "scores": out_s[last], "rows": out_r[last]}
 
 
-def scan_roofline(rows, D, scan_ms, launches, kernel="k_scan<48,1,16,8>"):
-    alg = float(rows) * D * 2          # the scan always streams the bf16 tiled copy
+def scan_kernel_name(D, B=64):
+    """The dominant kernel of a <= 64-query batch as the library launches it (crh_index.hip, enqueue_batch): the one-launch
+    scan (sample tiles + thresholds + every other tile) unless it is switched off or the width has no instance."""
+    ks = D // 16
+    qb = 1 if D == 1536 else 2
+    if os.environ.get("CODERAG_HIP_FUSED_SCAN", "1")[:1] != "0" and ks in (24, 48, 96):
+        return f"k_scan_fused<{ks},16,8,{qb}>"
+    return f"k_scan<{ks},1,16,8,{qb}>"
+
+
+def scan_roofline(rows, D, scan_ms, launches, kernel=None):
+    kernel = kernel or scan_kernel_name(D)
+    alg = float(rows) * D * 2          # the scan always streams the bf16 tiled copy (the one-launch form: exactly once)
     ach = alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
             "kernel": kernel, "kernel_ms": scan_ms, "launches": launches, "algorithmic_bytes_per_launch": alg}
@@ -468,7 +479,7 @@ def run(args, json_fd) -> None:
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_scan.json")))
-        if int(pmc.get("rows", -1)) == N:
+        if int(pmc.get("rows", -1)) == N and pmc.get("kernel") == scan_kernel_name(D):
             traffic = float(pmc["hbm_read_bytes_corrected"]) + float(pmc["hbm_write_bytes"])
     except (OSError, ValueError, KeyError):
         pass

@@ -1,0 +1,419 @@
+// crh_i8.hpp -- the int8 NOMINATION copy of the corpus and the scan over it (round 3).
+//
+// The 64-query scan is HBM-bound on the bf16 rows (2 bytes per element, 96 % of the measured read ceiling), and the scan only
+// NOMINATES: every returned id and score is decided by k_select's canonical f32 arithmetic on the stored rows.  So the scan may
+// read a coarser copy, as long as no row of the true top-k can be missed.  This file keeps a second, 1-byte copy of every row,
+//     x_i = s_r * (X_i + d_i),   X_i = rint(x_i * 127 / max|x|) in [-127, 127],   s_r = max|x| / 127   (per row),
+// and quantises each canonical query to 15 bits, q_i = s_q * (Q_i + g_i), Q = 128 * H + L with H, L int8.  Then, in exact
+// integers, dot = 128 * sum X_i H_i + sum X_i L_i (two v_mfma_i32_32x32x32_i8 per 1-KiB piece and 32-query block) and
+//     | x.q - s_r s_q dot |  =  s_r s_q | d.Q + X.g + d.g |  <=  s_r s_q * B_q,
+//     B_q = dn * (|Q|_2 + gn) + 127 sqrt(D) * gn,        dn >= |d|_2 of EVERY row (kept by k_requant_i8), gn >= |g|_2
+// by Cauchy-Schwarz -- no assumption on the data.  Each row therefore has an interval [lo, hi] = s_r s_q (dot -+ B_q) -+ c that
+// contains its canonical score (c: the f32 summation-order / store-rounding allowance the bf16 scan's margin already used).
+//   * threshold: tau_q = k-th largest over the sample tiles of max_rows(lo): k distinct rows score at least that, so the true
+//     k-th score does too;
+//   * nomination: every row with hi >= tau_q; the candidate carries (hi, lo);
+//   * k_select<.., I8>: L = k-th largest lo of the candidates (again a lower bound of the true k-th score), survivors = hi >= L,
+//     canonical re-score and exact top-k as before.
+// Results are bit-identical to the bf16 scan's and the oracle's.  On N(0, I)/sqrt(D) rows at D = 768: s_r ~ 9.6e-4, |d| ~ 8.0
+// (max 8.6), interval half-width ~ 8.3e-3 = 0.23 sigma of the score distribution; ~33 k candidates and ~700 survivors per query
+// and 10M rows, against a pass that reads 7.68 + 0.04 GB instead of 15.36 GB.  Rows with outlier elements get a large s_r and
+// are simply nominated more often; when the candidate buffers overflow the host re-runs the batch on the bf16 scan
+// (finish_pending) and, after repeated overflows, leaves the int8 copy unused for that index.
+//
+// Layout of the copy: tile = 32 rows; piece p of a tile = 1 KiB = elements [32p, 32p + 32) of its 32 rows as ONE MFMA operand
+// (lane l: row l & 31, elements 32p + 16 (l >> 5) .. + 15, one byte each).  Pieces of a tile are consecutive: D / 32 KiB per tile.
+// The copy is derived from the bf16 tiles (k_requant_i8), never stored in snapshots, and brought up to date lazily before a scan.
+#pragma once
+
+namespace crh {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
+constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H in [-127, 127], L in [-64, 63]
+
+// ------------------------------------------------------------------ bf16 tiles -> int8 tiles + per-row scale
+// One wave per tile.  dn_bits: f32 bits of the running maximum of |d|_2 (+ allowance for the f32 evaluation) over all rows
+// ever quantised; positive floats order like their bits, so atomicMax keeps it.
+__global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt, u32x4 *__restrict__ x8, float *__restrict__ srow,
+                                                   unsigned int *__restrict__ dn_bits, int64_t t0, int ksteps)
+{
+    const int64_t tile = t0 + blockIdx.x;
+    const int lane = threadIdx.x, row = lane & 31, hh = lane >> 5;
+    const u32x4 *tp = xt + (size_t)tile * ksteps * 64;
+    float m = 0.f;
+    for (int s = 0; s < ksteps; ++s) {
+        const u32x4 v = tp[s * 64 + lane];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m = fmaxf(m, fabsf(bf16_bits_f32(w[e] & 0xffffu)));
+            m = fmaxf(m, fabsf(bf16_bits_f32(w[e] >> 16)));
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (!(m < INFINITY)) m = 0.f;                       // (a row holding inf / nan: quantised to zeros, scale 0 -- see below)
+    const float s_r = m / 127.0f;
+    const float inv = m > 0.f ? 127.0f / m : 0.f;
+    float dsq = 0.f;
+    const int ks8 = ksteps >> 1;
+    for (int p = 0; p < ks8; ++p) {
+        const int s = 2 * p + hh;                        // bf16 piece holding elements [32p + 16hh, + 16) of the tile's rows
+        const u32x4 a = tp[s * 64 + row], b = tp[s * 64 + 32 + row];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float x = bf16_bits_f32(t ? (w[e] >> 16) : (w[e] & 0xffffu));
+                float y = x * inv;
+                y = (y == y) ? y : 0.f;
+                float X = rintf(y);
+                X = fminf(fmaxf(X, -127.f), 127.f);
+                const float d = y - X;
+                dsq = fmaf(d, d, dsq);
+                const int j = 2 * e + t;                 // byte j of the lane's 16
+                o[j >> 2] |= ((uint32_t)(int)X & 0xffu) << (8 * (j & 3));
+            }
+        }
+        u32x4 pk;
+        pk.x = o[0];
+        pk.y = o[1];
+        pk.z = o[2];
+        pk.w = o[3];
+        x8[((size_t)tile * ks8 + p) * 64 + lane] = pk;
+    }
+    dsq += __shfl_xor(dsq, 32);
+    // |d| as evaluated + what the f32 evaluation can hide: x * inv is off by <= 127 * 2^-23 per element, and s_r * inv differs
+    // from 1 by <= 2^-22, which moves every d_i by <= 127 * 2^-22: together < 1.3e-3 over 1536 elements
+    float dn = sqrtf(dsq) * 1.0001f + 2e-3f;
+    if (m == 0.f) dn = 0.f;
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) dn = fmaxf(dn, __shfl_xor(dn, d));
+    if (lane < 32) srow[(size_t)tile * 32 + row] = s_r;
+    if (lane == 0 && dn > 0.f) atomicMax(dn_bits, f32_bits(dn));
+}
+
+// ------------------------------------------------------------------ canonical queries -> 15-bit integer images
+// One wave per query slot (64 of them; slots >= nq hold zero queries).  qn: the canonical queries k_prep_queries wrote.
+// qfrag8: [QB][2 (H, L)][KS8][64] u32x4 MFMA operand pieces (lane l: query 32 b + (l & 31), elements 32p + 16 (l >> 5) .. + 15).
+// qpar:   [64][4] = s_q, |Q|_2, gn (bound of |g|_2), 0.
+__global__ __launch_bounds__(64) void k_prep_queries_i8(const float *__restrict__ qn, int dim, u32x4 *__restrict__ qfrag8,
+                                                        float *__restrict__ qpar)
+{
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    const float *src = qn + (size_t)qi * dim;
+    const int ks8 = dim >> 5, qb = qi >> 5, c = qi & 31;
+    float m = 0.f;
+    for (int i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (!(m < INFINITY)) m = 0.f;
+    const float s_q = m / kI8QueryLevels;
+    const float inv = m > 0.f ? kI8QueryLevels / m : 0.f;
+    float qsq = 0.f, gsq = 0.f;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(qfrag8);
+    for (int c8 = lane; c8 < (dim >> 3); c8 += 64) {      // 8 consecutive elements
+        uint32_t hb[2] = {0u, 0u}, lb[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = src[c8 * 8 + j] * inv;
+            y = (y == y) ? y : 0.f;
+            float Qf = rintf(y);
+            Qf = fminf(fmaxf(Qf, -kI8QueryLevels), kI8QueryLevels);
+            const float g = y - Qf;
+            qsq = fmaf(Qf, Qf, qsq);
+            gsq = fmaf(g, g, gsq);
+            const int Q = (int)Qf;
+            const int H = (Q + 64) >> 7;                  // floor((Q + 64) / 128): L = Q - 128 H in [-64, 63]
+            const int L = Q - 128 * H;
+            hb[j >> 2] |= ((uint32_t)H & 0xffu) << (8 * (j & 3));
+            lb[j >> 2] |= ((uint32_t)L & 0xffu) << (8 * (j & 3));
+        }
+        const int p = c8 >> 2, hh = (c8 >> 1) & 1, half8 = c8 & 1;
+        const size_t eh = (((size_t)(qb * 2 + 0) * ks8 + p) * 64 + hh * 32 + c) * 4 + half8 * 2;   // in 32-bit words
+        const size_t el = (((size_t)(qb * 2 + 1) * ks8 + p) * 64 + hh * 32 + c) * 4 + half8 * 2;
+        out32[eh] = hb[0];
+        out32[eh + 1] = hb[1];
+        out32[el] = lb[0];
+        out32[el + 1] = lb[1];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        qsq += __shfl_xor(qsq, d);
+        gsq += __shfl_xor(gsq, d);
+    }
+    if (lane == 0) {
+        // gn: |g| as evaluated + the f32 evaluation's share (y off by <= 16256 * 2^-23, s_q * inv off 1 by 2^-22 -> each g_i moves
+        // by < 6e-3; over 1536 elements < 0.24)
+        qpar[qi * 4 + 0] = s_q;
+        qpar[qi * 4 + 1] = sqrtf(qsq) * 1.0001f;
+        qpar[qi * 4 + 2] = m > 0.f ? sqrtf(gsq) * 1.001f + 0.25f : 0.f;
+        qpar[qi * 4 + 3] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ the scan over the int8 copy, one launch
+// Phases as k_scan_fused (sample tiles -> grid-wide wait -> thresholds -> grid-wide wait -> all tiles), with two differences:
+// the sample is G = min(4096, tiles) strided tiles walked by whoever's turn it is (the accumulators are not kept across the
+// waits: four accumulator sets per wave leave no room, and re-reading 100 MB of samples costs 1.3 % of the pass), and the
+// per-row interval arithmetic of the header comment replaces the single score.
+// LDS: query image QB * 2 * KS8 KiB (96 KB at D = 768) + the threshold phase's 16 + 8 + 5 KB.  WAVES = 8: 64 accumulator
+// registers + a 16-deep ring of loads per wave need more than the 128 registers a 16-wave workgroup leaves each wave.
+template <int KS8, int WAVES, int RING, int QB>
+__global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
+    const u32x4 *__restrict__ x8, const float *__restrict__ srow, const unsigned int *__restrict__ dn_bits,
+    const u32x4 *__restrict__ qfrag8, const float *__restrict__ qpar, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
+    float *__restrict__ gmax, float *__restrict__ tau_g, int k, float c_abs, float sqrt_dim, int nq, u32x4 *__restrict__ wave_lists,
+    int wave_cap, unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, float *__restrict__ qlo, int qcap,
+    SearchStatus *__restrict__ status, int wait_extra)
+{
+    static_assert(KS8 % RING == 0, "the ring must divide the pieces of a tile (slot s % RING holds piece s of every tile)");
+    constexpr int NT = WAVES * 64, NQS = QB * 32, NB = NT < 1024 ? NT : 1024;
+    __shared__ u32x4 qs[QB * 2 * KS8 * 64];
+    __shared__ uint32_t col[4096];
+    __shared__ unsigned int hist[(NT / 64) * 256];
+    __shared__ unsigned int bcast[2];
+    __shared__ unsigned int fast[NB + 256 + 2 * (NT / 64) + 8];
+    __shared__ float tau_s[NQS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+
+    for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
+    // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
+    const float dn = bits_f32(*dn_bits);
+    float sq[QB], Bq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = b * 32 + (lane & 31);
+        const float s_q = qpar[qi * 4 + 0], Qn = qpar[qi * 4 + 1], gn = qpar[qi * 4 + 2];
+        sq[b] = s_q;
+        // + 128: the f32 evaluation of 128 * dotH + dotL (both exact integers below 2^24) rounds once, by <= 2^30 * 2^-24 = 64
+        Bq[b] = (dn * (Qn + gn) + 127.0f * sqrt_dim * gn) * 1.0001f + 128.0f;
+    }
+    __syncthreads();
+
+    const int total = gridDim.x * WAVES;
+    const int gw = blockIdx.x * WAVES + wave;
+    u32x4 *mylist = wave_lists + (size_t)gw * wave_cap;
+    unsigned int wcnt = 0;
+    auto tile_ptr = [&](int64_t tile) { return x8 + (size_t)tile * (KS8 * 64) + lane; };
+
+    u32x4 ring[RING];
+    // one tile: KS8 x (wait for the oldest load, four MFMAs, refill the slot RING pieces ahead -- past the tile's end from `xn`)
+    auto scan_tile = [&](const u32x4 *xp, const u32x4 *xn, i32x16 (&acc)[QB][2]) {
+        asm volatile("" ::: "memory");   // (keeps the query image out of the loop-invariant registers, as in k_scan)
+        u32x4 bq[QB][2];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            bq[b][0] = qs[((b * 2 + 0) * KS8) * 64 + lane];
+            bq[b][1] = qs[((b * 2 + 1) * KS8) * 64 + lane];
+        }
+#pragma unroll
+        for (int s = 0; s < KS8; ++s) {
+            // order pinned by the sched_barrier: next piece's query operands (LDS), this piece's four MFMAs, the refill
+            const int s1 = (s + 1 < KS8) ? s + 1 : s;
+            u32x4 nb[QB][2];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                nb[b][0] = qs[((b * 2 + 0) * KS8 + s1) * 64 + lane];
+                nb[b][1] = qs[((b * 2 + 1) * KS8 + s1) * 64 + lane];
+            }
+            nt_wait<RING - 1>(ring[s % RING]);
+            const i32x4 xa = __builtin_bit_cast(i32x4, ring[s % RING]);
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                acc[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][0]), acc[b][0], 0, 0, 0);
+                acc[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][1]), acc[b][1], 0, 0, 0);
+            }
+            const int sp = s + RING;
+            const u32x4 *src = (sp < KS8) ? xp + sp * 64 : xn + (sp - KS8) * 64;
+            nt_load(ring[s % RING], src);
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                bq[b][0] = nb[b][0];
+                bq[b][1] = nb[b][1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // the intervals of a tile's 16 x QB accumulators of this lane, given the tile's 32 row scales (scalar registers: the tile is
+    // wave-uniform).  The two candidates of a select are made opaque first: left alone, the compiler turns the select into ONE
+    // load with a lane-dependent index, i.e. spills the scales to scratch and reads them back through the vector-memory counter.
+    auto intervals = [&](const i32x16 (&acc)[QB][2], const float (&sr)[32], float (&lo)[QB][16], float (&hi)[QB][16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowa = (r & 3) + 8 * (r >> 2);
+            float sa = sr[rowa], sb = sr[rowa + 4];
+            asm volatile("" : "+v"(sa), "+v"(sb));
+            const float s_r = h ? sb : sa;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const float f = fmaf((float)acc[b][0][r], 128.0f, (float)acc[b][1][r]);
+                const float w = s_r * sq[b];
+                hi[b][r] = fmaf(w, f + Bq[b], c_abs);
+                lo[b][r] = fmaf(w, f - Bq[b], -c_abs);
+            }
+        }
+    };
+    auto prime = [&](const u32x4 *xp) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
+    };
+
+    // ---- 1. sample tiles g = gw, gw + total, ...: per query the largest LOWER end among the tile's valid rows
+    {
+        int g = gw;
+        if (g < G) prime(tile_ptr((int64_t)g * S));
+        while (g < G) {
+            const int gn_ = g + total;
+            const int64_t tile = (int64_t)g * S;
+            const u32x4 *xp = tile_ptr(tile);
+            const u32x4 *xn = gn_ < G ? tile_ptr((int64_t)gn_ * S) : (gw < ntiles ? tile_ptr(gw) : xp);
+            const uint32_t vmask = rowmask[tile];
+            float sr[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
+            i32x16 acc[QB][2] = {};
+            scan_tile(xp, xn, acc);
+            float lo[QB][16], hi[QB][16];
+            intervals(acc, sr, lo, hi);
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    m = fmaxf(m, ((vmask >> row) & 1u) ? lo[b][r] : -INFINITY);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (h == 0) gmax[(size_t)(b * 32 + lane) * G + g] = m;
+            }
+            g = gn_;
+        }
+        if (gw >= G && gw < ntiles) prime(tile_ptr(gw));   // waves without a sample tile: start the main stream now
+    }
+    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
+
+    // ---- 2. thresholds: workgroup q owns query q (no margin: the intervals carry it)
+    for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
+        float t = -INFINITY;
+        if (q >= nq) {
+            t = INFINITY;
+        } else if (G >= k) {
+            for (int i = tid; i < G; i += NT) col[i] = ord_f32(gmax[(size_t)q * G + i]);
+            __syncthreads();
+            const uint32_t key = wg_kth_largest_fast<NT, NB, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k,
+                                                                  ord_f32(-INFINITY), fast, hist, bcast);
+            t = unord_f32(key);
+            __syncthreads();
+        }
+        if (tid == 0) tau_g[q] = t;
+    }
+    const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
+    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    if (tid < NQS) tau_s[tid] = tau_g[tid];
+    __syncthreads();
+    float tq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) tq[b] = tau_s[b * 32 + (lane & 31)];
+
+    // ---- 3. every tile: rows whose UPPER end reaches the query's threshold become candidates (hi, row, query, lo)
+    int i = gw;
+    const u32x4 *xp = tile_ptr(i < ntiles ? i : 0);
+    while (i < ntiles) {
+        const int inext = i + total;
+        const int64_t tile = i;
+        const u32x4 *xn = (inext < ntiles) ? tile_ptr(inext) : xp;
+        const uint32_t vmask = rowmask[tile];
+        float sr[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
+        i32x16 acc[QB][2] = {};
+        scan_tile(xp, xn, acc);
+        float lo[QB][16], hi[QB][16];
+        intervals(acc, sr, lo, hi);
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float mh = hi[b][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mh = fmaxf(mh, hi[b][r]);
+            any = any || (mh >= tq[b]);
+        }
+        if (__ballot(any) != 0ull && vmask != 0u) {
+            const uint32_t rowbase = (uint32_t)(tile * 32);
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool pass = ((vmask >> row) & 1u) && (hi[b][r] >= tq[b]);
+                    const unsigned long long pm = __ballot(pass);
+                    if (pm != 0ull) {
+                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+                        const unsigned int pos = wcnt + pre;
+                        if (pass && pos < (unsigned int)wave_cap) {
+                            u32x4 e;
+                            e.x = f32_bits(hi[b][r]);
+                            e.y = rowbase + row;
+                            e.z = (uint32_t)(b * 32 + (lane & 31));
+                            e.w = f32_bits(lo[b][r]);
+                            mylist[pos] = e;
+                        }
+                        wcnt += (unsigned int)__popcll(pm);
+                    }
+                }
+            }
+        }
+        xp = xn;
+        i = inext;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the last tile are still in flight
+
+    // ---- hand the workgroup's candidates over to the per-query lists (as k_scan does; the lower ends go to qlo)
+    __syncthreads();
+    unsigned int *wc = reinterpret_cast<unsigned int *>(qs);  // [WAVES] counts, [64] hist, [64] base, [64] off
+    unsigned int *qh = wc + WAVES;
+    unsigned int *base = qh + 64;
+    unsigned int *off = base + 64;
+    if (lane == 0) {
+        wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+        atomicMax(&status->max_wave_cnt, wcnt);
+        if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
+    }
+    if (tid < 64) {
+        qh[tid] = 0u;
+        off[tid] = 0u;
+    }
+    __syncthreads();
+    const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
+    for (int w = 0; w < WAVES; ++w) {
+        const unsigned int n = wc[w];
+        for (unsigned int e = tid; e < n; e += NT) atomicAdd(&qh[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) base[tid] = qh[tid] ? atomicAdd(&qcount[tid], qh[tid]) : 0u;
+    __syncthreads();
+    for (int w = 0; w < WAVES; ++w) {
+        const unsigned int n = wc[w];
+        for (unsigned int e = tid; e < n; e += NT) {
+            const u32x4 cnd = wl[(size_t)w * wave_cap + e];
+            const unsigned int q = cnd.z & 63u;
+            const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+            if (idx < (unsigned int)qcap) {
+                u32x2 o;
+                o.x = cnd.x;
+                o.y = cnd.y;
+                qlist[(size_t)q * qcap + idx] = o;
+                qlo[(size_t)q * qcap + idx] = bits_f32(cnd.w);
+            }
+        }
+    }
+}
+
+}  // namespace crh

@@ -12,6 +12,7 @@
 
 #include "crh_common.h"
 #include "crh_kernels.hpp"
+#include "crh_i8.hpp"
 
 namespace crh {
 std::string &last_error_ref()
@@ -29,6 +30,8 @@ constexpr int kWaves = 16;      // waves per scan workgroup (one workgroup per C
 constexpr int kRing = 8;        // 1-KiB loads in flight per wave
 constexpr int kWideWaves = 8;   // waves per k_scan_wide workgroup: each sees every tile of its workgroup for 32 queries, so the
                                 // workgroup's share of the candidate workspace is cut into 8 lists of 2 x wave_cap entries
+constexpr int kI8Waves = 8;     // k_scan_i8: waves per workgroup, 1-KiB loads in flight per wave (crh_i8.hpp)
+constexpr int kI8Ring = 12;
 constexpr int kStatusSlots = 1024;
 constexpr int64_t kWorkspaceBudget = 48LL << 30;
 
@@ -40,6 +43,7 @@ struct Pending {
     float *out_s;
     int64_t *out_r;
     int slot;
+    bool used_i8;   // the batch was nominated from the int8 copy (an overflow then sends it to the bf16 scan, not to bigger buffers)
 };
 
 }  // namespace
@@ -49,6 +53,14 @@ struct crh_index {
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     bool fused_scan = true;   // <= batch_q queries: seed scan + threshold + main scan in one launch (CODERAG_HIP_FUSED_SCAN=0: three)
+    // int8 nomination copy (crh_i8.hpp): derived from xt, brought up to date before a scan (i8_sync); tiles >= i8_dirty_from are stale
+    bool i8 = false;          // <= batch_q queries are nominated from the copy (dim 384 / 768 / 1536; CODERAG_HIP_I8=0: never)
+    u32x4 *x8 = nullptr;
+    float *srow = nullptr;
+    unsigned int *i8stat = nullptr;
+    int64_t x8_cap_tiles = 0, i8_dirty_from = 0;
+    int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused)
+    bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -63,8 +75,8 @@ struct crh_index {
     struct Workspace {
         int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
         int64_t ws_mask_tiles = 0;
-        float *qn = nullptr, *gmax = nullptr, *tau = nullptr;
-        u32x4 *qfrag = nullptr, *wave_lists = nullptr;
+        float *qn = nullptr, *gmax = nullptr, *tau = nullptr, *qpar = nullptr, *qlo = nullptr;
+        u32x4 *qfrag = nullptr, *qfrag8 = nullptr, *wave_lists = nullptr;
         uint32_t *effmask = nullptr;
         u32x2 *qlist = nullptr;
         unsigned long long *skeys = nullptr;
@@ -144,6 +156,8 @@ int ensure_workspace(crh_index *h, crh_index::Workspace &w, int wave_cap, int qc
     if (!w.qn) CRH_TRY(dev_alloc(&w.qn, (int64_t)kWideQ * h->dim));
     if (!w.qfrag) CRH_TRY(dev_alloc(&w.qfrag, (int64_t)(kWideQ / 32) * h->ksteps * 64));
     if (!w.tau) CRH_TRY(dev_alloc(&w.tau, kWideQ));
+    if (h->i8 && !w.qfrag8) CRH_TRY(dev_alloc(&w.qfrag8, (int64_t)(kMaxQ / 32) * 2 * (h->dim / 32) * 64));
+    if (h->i8 && !w.qpar) CRH_TRY(dev_alloc(&w.qpar, kMaxQ * 4));
     if (!h->status) {
         CRH_TRY(dev_alloc(&h->status, kStatusSlots));
         CRH_HIP(hipMemset(h->status, 0, sizeof(SearchStatus) * kStatusSlots));
@@ -174,9 +188,11 @@ int ensure_workspace(crh_index *h, crh_index::Workspace &w, int wave_cap, int qc
         if (bytes > kWorkspaceBudget) return fail(CRH_E_CAPACITY, "per-query candidate lists of %lld bytes exceed the budget", (long long)bytes);
         dev_free(w.qlist);
         dev_free(w.skeys);
+        dev_free(w.qlo);
         w.ws_qcap = 0;
         CRH_TRY(dev_alloc(&w.qlist, (int64_t)kWideQ * qcap));
         CRH_TRY(dev_alloc(&w.skeys, (int64_t)kWideQ * qcap));
+        if (h->i8) CRH_TRY(dev_alloc(&w.qlo, (int64_t)kMaxQ * qcap));
         w.ws_qcap = qcap;
     }
     return CRH_OK;
@@ -257,6 +273,64 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
     return CRH_OK;
 }
 
+// ---- int8 nomination (crh_i8.hpp)
+bool i8_use(const crh_index *h, int nq)
+{
+    return h->i8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan && h->seed_tiles == 4096;
+}
+
+// the copy covers the index: (re)allocate with the capacity, requantise the tiles touched since the last scan.  Running out of
+// memory for the copy is not an error: the index goes on with the bf16 scan.
+int i8_sync(crh_index *h, hipStream_t st)
+{
+    if (!h->i8) return CRH_OK;
+    const int64_t ntiles = ceil_div(h->count, kTileRows);
+    const int ks8 = h->dim / 32;
+    if (h->x8_cap_tiles < h->cap_tiles) {
+        dev_free(h->x8);
+        dev_free(h->srow);
+        h->x8_cap_tiles = 0;
+        bool ok = hipMalloc(reinterpret_cast<void **>(&h->x8), (size_t)h->cap_tiles * ks8 * 1024) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void **>(&h->srow), (size_t)h->cap_tiles * 32 * sizeof(float)) == hipSuccess;
+        if (ok && !h->i8stat)
+            ok = hipMalloc(reinterpret_cast<void **>(&h->i8stat), 16) == hipSuccess && hipMemset(h->i8stat, 0, 16) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            dev_free(h->x8);
+            dev_free(h->srow);
+            h->i8 = false;
+            return CRH_OK;
+        }
+        h->x8_cap_tiles = h->cap_tiles;
+        h->i8_dirty_from = 0;
+    }
+    if (h->i8_dirty_from < ntiles) {
+        hipLaunchKernelGGL(k_requant_i8, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->x8, h->srow, h->i8stat,
+                           h->i8_dirty_from, h->ksteps);
+        CRH_HIP(hipGetLastError());
+        h->i8_dirty_from = ntiles;
+    }
+    return CRH_OK;
+}
+
+int launch_scan_i8(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int ntiles, int G, int S, int k, float c_abs,
+                   int nq, int wave_cap, int qcap, SearchStatus *stt)
+{
+#define CRH_I8(KS8, RING, QB)                                                                                                          \
+    hipLaunchKernelGGL((k_scan_i8<KS8, kI8Waves, RING, QB>), dim3(blocks), dim3(kI8Waves * 64), 0, st, h->x8, h->srow, h->i8stat, w.qfrag8, \
+                       w.qpar, mask, ntiles, G, S, w.gmax, w.tau, k, c_abs, sqrtf((float)h->dim), nq, w.wave_lists, wave_cap, stt->qcount,     \
+                       w.qlist, w.qlo, qcap, stt, h->force_fallback == 2 ? 1 : 0)
+    switch (h->dim) {
+    case 384: CRH_I8(12, 12, 2); break;
+    case 768: CRH_I8(24, kI8Ring, 2); break;
+    case 1536: CRH_I8(48, kI8Ring, 1); break;
+    default: return fail(CRH_E_INTERNAL, "no int8 scan kernel for dim %d", h->dim);
+    }
+#undef CRH_I8
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 // the wide scan: dim 384 / 768 (the query block of a wave must fit its registers)
 template <int MODE>
 int launch_scan_wide(crh_index *h, crh_index::Workspace &w, hipStream_t st, const uint32_t *mask, int nitems, int stride, int nblk, int wave_cap, int qcap,
@@ -303,6 +377,34 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
     CRH_HIP(hipGetLastError());
 
+    // <= batch_q queries, nominated from the int8 copy (crh_i8.hpp): half the bytes of the pass, same results
+    if (i8_use(h, nq)) {
+        CRH_TRY(i8_sync(h, st));
+    }
+    if (i8_use(h, nq)) {   // (i8_sync may have given the copy up for lack of memory)
+        hipLaunchKernelGGL(k_prep_queries_i8, dim3(h->batch_q), dim3(64), 0, st, w.qn, h->dim, w.qfrag8, w.qpar);
+        CRH_HIP(hipGetLastError());
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
+        const int G8 = (int)std::min<int64_t>(4096, ntiles);
+        const int S8 = (int)std::max<int64_t>(1, ntiles / G8);
+        const float c_abs = 0.5f * margin + 1e-5f;
+        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
+        CRH_TRY(launch_scan_i8(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
+        if (h->dtype == CRH_DTYPE_F32)
+            hipLaunchKernelGGL((k_select<true, true>), dim3(nq), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+        else
+            hipLaunchKernelGGL((k_select<false, true>), dim3(nq), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+        CRH_HIP(hipGetLastError());
+        h->stats.rows += h->count;
+        h->stats.tiles += ntiles;
+        h->stats.seed_tiles += G8;
+        h->stats.batches += 1;
+        return CRH_OK;
+    }
+
     // <= batch_q queries at the default sample size: seed scan, threshold and main scan are ONE launch (k_scan_fused: every wave's
     // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
     // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
@@ -315,10 +417,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         CRH_TRY(launch_scan_fused(h, w, blocks, st, mask, (int)ntiles, Gf, Sf, k, margin, nq, wave_cap, qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
         if (h->dtype == CRH_DTYPE_F32)
-            hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         else
-            hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         CRH_HIP(hipGetLastError());
         h->stats.rows += h->count;
@@ -342,10 +444,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         CRH_TRY(launch_scan<1>(h, w, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
-        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     else
-        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     CRH_HIP(hipGetLastError());
     h->stats.rows += h->count;
@@ -383,14 +485,25 @@ int finish_pending(crh_index *h, hipStream_t st)
             }
         }
         int attempts = 0;
+        bool via_i8 = p.used_i8;
+        if (via_i8 && !(s.bar_timeout || s.wave_overflow || s.q_overflow)) h->i8_strikes = 0;
         while (s.bar_timeout || s.wave_overflow || s.q_overflow) {
-            if (++attempts > 5) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
+            if (++attempts > 6) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
             if (s.bar_timeout) {
-                // A grid-wide wait of the fused scan gave up: some workgroup was not resident for ~1 s (other streams' kernels
-                // holding CUs).  The batch's results are void; this index goes back to the three-launch form, which needs no
-                // co-residency, and the batch is run again.
+                // A grid-wide wait of the one-launch scan gave up: some workgroup was not resident for ~0.5 s (other streams'
+                // kernels holding CUs).  The batch's results are void; this index goes back to the three-launch form, which needs
+                // no co-residency, and the batch is run again.
                 h->fused_scan = false;
                 h->stats.fallback_used |= 2;
+            } else if (via_i8) {
+                // the int8 intervals of this data / this k are too wide for the candidate buffers: the batch goes to the bf16 scan
+                // (whose buffers regrow if they must); three such batches in a row and the copy is left unused
+                h->i8_strikes += 1;
+                h->i8_suppress = true;
+                h->stats.fallback_used |= 4;
+                via_i8 = false;
+                s.max_wave_cnt = 0;
+                s.max_qcount = 0;
             } else {
                 h->stats.fallback_used |= 1;
             }
@@ -400,7 +513,9 @@ int finish_pending(crh_index *h, hipStream_t st)
             CRH_TRY(ensure_workspace(h, w, wc, qc));
             const uint32_t *mask = nullptr;
             CRH_TRY(build_mask(h, w, p.filt, p.nfilt, &mask, st));
-            CRH_TRY(enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st));
+            const int rc = enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st);
+            h->i8_suppress = false;
+            CRH_TRY(rc);
             CRH_HIP(hipStreamSynchronize(st));
             CRH_HIP(hipMemcpy(&s, h->status, sizeof(SearchStatus), hipMemcpyDeviceToHost));
         }
@@ -469,6 +584,9 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
     {
         const char *e = getenv("CODERAG_HIP_FUSED_SCAN");
         h->fused_scan = !(e && e[0] == '0');
+        const char *e8 = getenv("CODERAG_HIP_I8");
+        h->i8 = h->fused_scan && dim != 1024 && !(e8 && e8[0] == '0');   // (dim 1024: the query image + the threshold phase exceed LDS)
+        if (h->i8) h->qcap = 131072;   // ~33 k candidates per query and 10M rows on Gaussian data (crh_i8.hpp)
     }
     h->dtype = dtype;
     h->ncols = n_code_cols;
@@ -513,7 +631,13 @@ int crh_index_destroy(crh_index *h)
         dev_free(w.effmask);
         dev_free(w.qlist);
         dev_free(w.skeys);
+        dev_free(w.qfrag8);
+        dev_free(w.qpar);
+        dev_free(w.qlo);
     }
+    dev_free(h->x8);
+    dev_free(h->srow);
+    dev_free(h->i8stat);
     dev_free(h->status);
     dev_free(h->stage_q);
     dev_free(h->stage_os);
@@ -586,6 +710,7 @@ static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device
         CRH_HIP(hipGetLastError());
         if (!on_device) CRH_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
     }
+    h->i8_dirty_from = std::min<int64_t>(h->i8_dirty_from, h->count / kTileRows);   // (the last tile may have been partly filled)
     h->count += n;
     h->alive_count += n;
     return CRH_OK;
@@ -721,6 +846,7 @@ int crh_index_compact(crh_index *h, int64_t *old_to_new_host, int64_t *rows_afte
 #undef CRH_CPT
     cleanup();
     h->count = new_count;
+    h->i8_dirty_from = 0;
     h->alive_count = new_count;
     if (rows_after) *rows_after = new_count;
     return CRH_OK;
@@ -782,6 +908,7 @@ int crh_index_import(crh_index *h, int64_t first_tile, int64_t n_tiles, int64_t 
     for (int c = 0; c < h->ncols; ++c)
         CRH_HIP(hipMemcpy(h->codes + (int64_t)c * h->cap_rows + r0, codes_host + (int64_t)c * nr, (size_t)nr * 4, hipMemcpyHostToDevice));
     h->count = rows_after;
+    h->i8_dirty_from = std::min<int64_t>(h->i8_dirty_from, first_tile);
     h->alive_count += alive_rows;
     return CRH_OK;
 }
@@ -805,6 +932,7 @@ int crh_index_clear(crh_index *h)
         CRH_HIP(hipMemset(h->alive, 0, (size_t)used_tiles * 4));
     }
     h->count = 0;
+    h->i8_dirty_from = 0;
     h->alive_count = 0;
     h->pending.clear();
     h->next_slot = 0;
@@ -986,6 +1114,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         // (the filter mask lives in the workspace: stream order puts its rebuild behind the previous batch's scan)
         CRH_TRY(build_mask(h, w, filters, n_filters, &mask, st));
         CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
+        p.used_i8 = h->count > 0 && i8_use(h, b);   // (as enqueue_batch just decided)
         h->pending.push_back(p);
     }
     if (!out_on_device || !queries_on_device) {

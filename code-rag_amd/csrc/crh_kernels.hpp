@@ -1331,8 +1331,11 @@ __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf3
 //      the canonical top-k is inside);
 //   3. re-score the survivors canonically, key = (ord(score) << 32) | ~row;
 //   4. exact top-k of the keys (descending score, ascending row), written with row_base added.
-template <bool F32>
-__global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist, const unsigned int *__restrict__ qcount,
+// I8 (the candidates come from k_scan_i8, crh_i8.hpp): an entry's score is the UPPER end of the row's interval and qlo holds the
+// lower ends; step 1 takes the k-th largest LOWER end, step 2 keeps every candidate whose UPPER end reaches it, no margin.
+template <bool F32, bool I8 = false>
+__global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist, const float *__restrict__ qlo,
+                                                  const unsigned int *__restrict__ qcount,
                                                   int qcap, unsigned long long *__restrict__ skeys,
                                                   const float *__restrict__ qn, const u32x4 *__restrict__ xt,
                                                   const float *__restrict__ xf32, int dim, int ksteps, int k,
@@ -1370,7 +1373,9 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
         return;
     }
     const u32x2 *ql = qlist + (size_t)q * qcap;
+    const float *qlq = I8 ? qlo + (size_t)q * qcap : nullptr;
     unsigned long long *sk = skeys + (size_t)q * qcap;
+    auto first_key = [&](unsigned int i) { return I8 ? ord_f32(qlq[i]) : ord_f32(bits_f32(ql[i].x)); };   // what step 1 ranks
     __syncthreads();
 
     // the four radix passes and the survivor cut all re-read the candidate scores: stage them in LDS once (one batch of
@@ -1379,17 +1384,17 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     const bool staged = M <= SCAP;
     if (staged) {
 #pragma unroll 4
-        for (unsigned int i = tid; i < M; i += NT) lscore[i] = ord_f32(bits_f32(ql[i].x));
+        for (unsigned int i = tid; i < M; i += NT) lscore[i] = first_key(i);
         __syncthreads();
     }
     const uint32_t akey = staged ? wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return lscore[i]; }, M, kk, 0u, fast, hist, bcast)
-                                 : wg_kth_largest<uint32_t, NT>([&](unsigned int i) { return ord_f32(bits_f32(ql[i].x)); }, M, kk, hist, bcast);
-    const float lower = unord_f32(akey) - margin;
-    const uint32_t lower_key = ord_f32(lower);
+                          : I8   ? wg_kth_largest_fast<NT, 1024, 256>(first_key, M, kk, 0u, fast, hist, bcast)   // (tens of thousands of candidates)
+                                 : wg_kth_largest<uint32_t, NT>(first_key, M, kk, hist, bcast);
+    const uint32_t lower_key = I8 ? akey : ord_f32(unord_f32(akey) - margin);
 
     for (unsigned int i0 = 0; i0 < M; i0 += NT) {     // (whole waves take part in every round: the compaction uses ballots)
         const unsigned int i = i0 + tid;
-        const uint32_t sc = i < M ? (staged ? lscore[i] : ord_f32(bits_f32(ql[i].x))) : 0u;
+        const uint32_t sc = i < M ? ((staged && !I8) ? lscore[i] : ord_f32(bits_f32(ql[i].x))) : 0u;
         const bool keep = i < M && sc >= lower_key;
         const unsigned long long bm = __ballot(keep);   // one LDS atomic per wave, not one per survivor
         unsigned int base = 0u;

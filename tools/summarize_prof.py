@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condense a tools/gpu_prof.sh output directory (rocprofv3 CSVs) into profiles/<name>.md + .json.
 
-    python tools/summarize_prof.py gpurun_out/prof_r1b profiles/r01_search_10M
+    python tools/summarize_prof.py gpurun_out/prof_r1b profiles/r01_search_10M [profiles/pmc_scan.json]
+
+With a third argument the corrected per-launch HBM bytes of the headline scan kernel (the <= 64-query scan with the largest
+share of the trace) are also written there, in the form bench.py reads for `roofline.traffic`.
 
 FETCH_SIZE is doubled for the scan kernel as MI355X_MICROARCH.md (section HBM) prescribes for wide
 coalesced 16 B/lane streaming reads on gfx950; WRITE_SIZE is taken as is.  Both are KiB in the CSV.
@@ -20,7 +23,7 @@ def short(name: str) -> str:
     return name[-70:]
 
 
-def main(src: str, dst: str) -> None:
+def main(src: str, dst: str, pmc_scan: str | None = None) -> None:
     out = {"source": src, "kernels": {}, "bench_line": None}
     logs = glob.glob(os.path.join(src, "**", "trace.log"), recursive=True)
     if logs:
@@ -68,7 +71,24 @@ def main(src: str, dst: str) -> None:
                      f"{pmc.get('FETCH_SIZE', {}).get('mean', float('nan')):.0f} | {pmc.get('WRITE_SIZE', {}).get('mean', float('nan')):.0f} | "
                      f"{k.get('hbm_read_bytes_corrected', float('nan')):.4g} |\n")
     print("wrote", dst + ".md")
+    if pmc_scan:
+        cands = [(k.get("pct", 0.0), kn) for kn, k in out["kernels"].items()
+                 if "k_scan" in kn and "wide" not in kn and "hbm_read_bytes_corrected" in k and "hbm_write_bytes" in k]
+        if not cands or not out["bench_line"]:
+            raise SystemExit("no scan kernel with FETCH_SIZE and WRITE_SIZE rows (or no bench line) under " + src)
+        kn = max(cands)[1]
+        k = out["kernels"][kn]
+        m = re.search(r"(k_scan\w*<[\d, ]+>)", kn)
+        name = m.group(1).replace(" ", "") if m else kn
+        rows = int(re.search(r"(\d+)x\d+ ", out["bench_line"]["config"]["workload"].split(": ", 1)[1]).group(1))
+        json.dump({"source": f"{dst}.json ({src}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py)",
+                   "kernel": name, "rows": rows, "fetch_size_kib_mean": k["pmc"]["FETCH_SIZE"]["mean"],
+                   "write_size_kib_mean": k["pmc"]["WRITE_SIZE"]["mean"], "hbm_read_bytes_corrected": k["hbm_read_bytes_corrected"],
+                   "hbm_write_bytes": k["hbm_write_bytes"],
+                   "correction": "FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests of wide coalesced 16 B/lane streams at 64 B: "
+                                 "MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024"}, open(pmc_scan, "w"), indent=1)
+        print("wrote", pmc_scan, "for", name)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
