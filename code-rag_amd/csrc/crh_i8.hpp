@@ -178,12 +178,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     __shared__ unsigned int bcast[2];
     __shared__ unsigned int fast[NB + 256 + 2 * (NT / 64) + 8];
     __shared__ float tau_s[NQS];
+    __shared__ unsigned int qcnt_l[64];   // candidates of this workgroup per query, counted as they are emitted
+    __shared__ unsigned int wpre[WAVES + 1];
+    __shared__ int next_m;                // tiles handed out so far to this workgroup's waves (main loop)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
+    CRH_STAMP(0);
     for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
+    if (tid < 64) qcnt_l[tid] = 0u;
+    if (tid == 0) next_m = WAVES;
     // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
     const float dn = bits_f32(*dn_bits);
     float sq[QB], Bq[QB];
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     // the intervals of a tile's 16 x QB accumulators of this lane, given the tile's 32 row scales (scalar registers: the tile is
     // wave-uniform).  The two candidates of a select are made opaque first: left alone, the compiler turns the select into ONE
     // load with a lane-dependent index, i.e. spills the scales to scratch and reads them back through the vector-memory counter.
-    auto intervals = [&](const i32x16 (&acc)[QB][2], const float (&sr)[32], float (&lo)[QB][16], float (&hi)[QB][16]) {
+    auto intervals = [&](const i32x16 (&acc)[QB][2], const float (&sr)[32], float (&hi)[QB][16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rowa = (r & 3) + 8 * (r >> 2);
@@ -254,11 +260,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
                 const float f = fmaf((float)acc[b][0][r], 128.0f, (float)acc[b][1][r]);
-                const float w = s_r * sq[b];
-                hi[b][r] = fmaf(w, f + Bq[b], c_abs);
-                lo[b][r] = fmaf(w, f - Bq[b], -c_abs);
+                hi[b][r] = fmaf(s_r * sq[b], f + Bq[b], c_abs);
             }
         }
+    };
+    // the lower end of an interval from its upper end: hi - 2 (s_r s_q B_q + c), one more allowance for the f32 evaluation
+    auto lower_end = [&](float hi_v, const float (&sr)[32], int b, int r) {
+        const int rowa = (r & 3) + 8 * (r >> 2);
+        float sa = sr[rowa], sb = sr[rowa + 4];
+        asm volatile("" : "+v"(sa), "+v"(sb));
+        const float s_r = h ? sb : sa;
+        return hi_v - 2.0f * fmaf(s_r * sq[b], Bq[b], c_abs) - 2e-6f;
     };
     auto prime = [&](const u32x4 *xp) {
 #pragma unroll
@@ -280,15 +292,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
             i32x16 acc[QB][2] = {};
             scan_tile(xp, xn, acc);
-            float lo[QB][16], hi[QB][16];
-            intervals(acc, sr, lo, hi);
+            float hi[QB][16];
+            intervals(acc, sr, hi);
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
                 float m = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    m = fmaxf(m, ((vmask >> row) & 1u) ? lo[b][r] : -INFINITY);
+                    m = fmaxf(m, ((vmask >> row) & 1u) ? lower_end(hi[b][r], sr, b, r) : -INFINITY);
                 }
                 m = fmaxf(m, __shfl_xor(m, 32));
                 if (h == 0) gmax[(size_t)(b * 32 + lane) * G + g] = m;
@@ -297,7 +309,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         }
         if (gw >= G && gw < ntiles) prime(tile_ptr(gw));   // waves without a sample tile: start the main stream now
     }
+    CRH_STAMP(2);
     grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
+    CRH_STAMP(3);
 
     // ---- 2. thresholds: workgroup q owns query q (no margin: the intervals carry it)
     for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
@@ -315,7 +329,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         if (tid == 0) tau_g[q] = t;
     }
     const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
+    CRH_STAMP(4);
     grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
     __syncthreads();
     float tq[QB];
@@ -326,7 +342,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     int i = gw;
     const u32x4 *xp = tile_ptr(i < ntiles ? i : 0);
     while (i < ntiles) {
+        // which wave takes the workgroup's next tile is decided as they go: the SIMD issues its older wave first, and with a fixed
+        // list per wave the younger four finished 80-130 us after the older four (stamps, round 3) on half the loads in flight
+#ifndef CRH_I8_STATIC
+        int mn = 0;
+        if (lane == 0) mn = atomicAdd(&next_m, 1);
+        mn = __builtin_amdgcn_readfirstlane(mn);
+        const int inext = (mn / WAVES) * total + (int)blockIdx.x * WAVES + (mn % WAVES);
+#else
         const int inext = i + total;
+#endif
         const int64_t tile = i;
         const u32x4 *xn = (inext < ntiles) ? tile_ptr(inext) : xp;
         const uint32_t vmask = rowmask[tile];
@@ -335,8 +360,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
         i32x16 acc[QB][2] = {};
         scan_tile(xp, xn, acc);
-        float lo[QB][16], hi[QB][16];
-        intervals(acc, sr, lo, hi);
+        float hi[QB][16];
+        intervals(acc, sr, hi);
         bool any = false;
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
@@ -362,8 +387,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
                             e.x = f32_bits(hi[b][r]);
                             e.y = rowbase + row;
                             e.z = (uint32_t)(b * 32 + (lane & 31));
-                            e.w = f32_bits(lo[b][r]);
+                            e.w = f32_bits(lower_end(hi[b][r], sr, b, r));
                             mylist[pos] = e;
+                            atomicAdd(&qcnt_l[b * 32 + (lane & 31)], 1u);
                         }
                         wcnt += (unsigned int)__popcll(pm);
                     }
@@ -374,46 +400,70 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         i = inext;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the last tile are still in flight
+    CRH_STAMP(6);
+#ifdef CRH_FUSED_STAMPS
+    if (lane == 0 && blockIdx.x < 256 && wave < 16) g_fused_stamps[256 * 8 + blockIdx.x * 16 + wave] = wall_clock64();
+#endif
 
-    // ---- hand the workgroup's candidates over to the per-query lists (as k_scan does; the lower ends go to qlo)
-    __syncthreads();
-    unsigned int *wc = reinterpret_cast<unsigned int *>(qs);  // [WAVES] counts, [64] hist, [64] base, [64] off
-    unsigned int *qh = wc + WAVES;
-    unsigned int *base = qh + 64;
-    unsigned int *off = base + 64;
+    // ---- hand the workgroup's candidates over to the per-query lists: the per-query counts are known (counted at emit), so
+    // one range per (workgroup, query) is reserved with 64 global atomics and ONE sweep copies the entries, eight loads deep
     if (lane == 0) {
-        wc[wave] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
+        wpre[wave + 1] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
         atomicMax(&status->max_wave_cnt, wcnt);
         if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
     }
+    __syncthreads();
+    unsigned int *base = reinterpret_cast<unsigned int *>(qs);   // [64] start of this workgroup's range in each query's list
+    unsigned int *off = base + 64;                                // [64] entries placed so far
     if (tid < 64) {
-        qh[tid] = 0u;
+        const unsigned int n = qcnt_l[tid];
+        base[tid] = n ? atomicAdd(&qcount[tid], n) : 0u;
         off[tid] = 0u;
     }
-    __syncthreads();
-    const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
-    for (int w = 0; w < WAVES; ++w) {
-        const unsigned int n = wc[w];
-        for (unsigned int e = tid; e < n; e += NT) atomicAdd(&qh[wl[(size_t)w * wave_cap + e].z & 63u], 1u);
+    if (tid == 0) {
+        unsigned int run = 0u;
+        for (int w = 0; w < WAVES; ++w) {
+            const unsigned int n = wpre[w + 1];
+            wpre[w] = run;
+            run += n;
+        }
+        wpre[WAVES] = run;
     }
     __syncthreads();
-    if (tid < 64) base[tid] = qh[tid] ? atomicAdd(&qcount[tid], qh[tid]) : 0u;
-    __syncthreads();
-    for (int w = 0; w < WAVES; ++w) {
-        const unsigned int n = wc[w];
-        for (unsigned int e = tid; e < n; e += NT) {
-            const u32x4 cnd = wl[(size_t)w * wave_cap + e];
-            const unsigned int q = cnd.z & 63u;
-            const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
-            if (idx < (unsigned int)qcap) {
-                u32x2 o;
-                o.x = cnd.x;
-                o.y = cnd.y;
-                qlist[(size_t)q * qcap + idx] = o;
-                qlo[(size_t)q * qcap + idx] = bits_f32(cnd.w);
+    const unsigned int nall = wpre[WAVES];
+    const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
+    for (unsigned int e0 = tid; e0 < nall; e0 += NT * 8) {
+        u32x4 cnd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int e = e0 + j * NT;
+            if (e < nall) {
+                int w = 0;
+#pragma unroll
+                for (int t = 1; t < WAVES; ++t) w += (e >= wpre[t]) ? 1 : 0;
+                cnd[j] = wl[(size_t)w * wave_cap + (e - wpre[w])];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int e = e0 + j * NT;
+            if (e < nall) {
+                const unsigned int q = cnd[j].z & 63u;
+                const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
+                if (idx < (unsigned int)qcap) {
+                    u32x2 o;
+                    o.x = cnd[j].x;
+                    o.y = cnd[j].y;
+                    qlist[(size_t)q * qcap + idx] = o;
+                    qlo[(size_t)q * qcap + idx] = bits_f32(cnd[j].w);
+                }
             }
         }
     }
+#ifdef CRH_FUSED_STAMPS
+    __syncthreads();
+    CRH_STAMP(7);
+#endif
 }
 
 }  // namespace crh

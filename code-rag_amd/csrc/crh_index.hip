@@ -31,7 +31,11 @@ constexpr int kRing = 8;        // 1-KiB loads in flight per wave
 constexpr int kWideWaves = 8;   // waves per k_scan_wide workgroup: each sees every tile of its workgroup for 32 queries, so the
                                 // workgroup's share of the candidate workspace is cut into 8 lists of 2 x wave_cap entries
 constexpr int kI8Waves = 8;     // k_scan_i8: waves per workgroup, 1-KiB loads in flight per wave (crh_i8.hpp)
-constexpr int kI8Ring = 12;
+#ifndef CRH_I8_RING
+#define CRH_I8_RING 8
+#endif
+constexpr int kI8Ring = CRH_I8_RING;
+constexpr int kI8SelectParts = 4;   // workgroups per query in k_select behind the int8 scan (64 queries x 4 = the chip)
 constexpr int kStatusSlots = 1024;
 constexpr int64_t kWorkspaceBudget = 48LL << 30;
 
@@ -79,7 +83,7 @@ struct crh_index {
         u32x4 *qfrag = nullptr, *qfrag8 = nullptr, *wave_lists = nullptr;
         uint32_t *effmask = nullptr;
         u32x2 *qlist = nullptr;
-        unsigned long long *skeys = nullptr;
+        unsigned long long *skeys = nullptr, *skeys2 = nullptr;
     };
     Workspace ws;
     SearchStatus *status = nullptr;
@@ -189,10 +193,12 @@ int ensure_workspace(crh_index *h, crh_index::Workspace &w, int wave_cap, int qc
         dev_free(w.qlist);
         dev_free(w.skeys);
         dev_free(w.qlo);
+        dev_free(w.skeys2);
         w.ws_qcap = 0;
         CRH_TRY(dev_alloc(&w.qlist, (int64_t)kWideQ * qcap));
         CRH_TRY(dev_alloc(&w.skeys, (int64_t)kWideQ * qcap));
         if (h->i8) CRH_TRY(dev_alloc(&w.qlo, (int64_t)kMaxQ * qcap));
+        if (h->i8) CRH_TRY(dev_alloc(&w.skeys2, (int64_t)kMaxQ * qcap));
         w.ws_qcap = qcap;
     }
     return CRH_OK;
@@ -392,10 +398,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         CRH_TRY(launch_scan_i8(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
         if (h->dtype == CRH_DTYPE_F32)
-            hipLaunchKernelGGL((k_select<true, true>), dim3(nq), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL((k_select<true, true>), dim3(nq, kI8SelectParts), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.skeys2, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         else
-            hipLaunchKernelGGL((k_select<false, true>), dim3(nq), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL((k_select<false, true>), dim3(nq, kI8SelectParts), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.skeys2, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         CRH_HIP(hipGetLastError());
         h->stats.rows += h->count;
@@ -417,10 +423,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         CRH_TRY(launch_scan_fused(h, w, blocks, st, mask, (int)ntiles, Gf, Sf, k, margin, nq, wave_cap, qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
         if (h->dtype == CRH_DTYPE_F32)
-            hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, (unsigned long long *)nullptr, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         else
-            hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+            hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, (unsigned long long *)nullptr, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
         CRH_HIP(hipGetLastError());
         h->stats.rows += h->count;
@@ -444,10 +450,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         CRH_TRY(launch_scan<1>(h, w, scan_blocks(h, ntiles), st, mask, (int)ntiles, 1, wave_cap, qcap, stt));
     if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
     if (h->dtype == CRH_DTYPE_F32)
-        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+        hipLaunchKernelGGL(k_select<true>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, (unsigned long long *)nullptr, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     else
-        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, w.qn, h->xt,
+        hipLaunchKernelGGL(k_select<false>, dim3(nq), dim3(1024), 0, st, w.qlist, (const float *)nullptr, stt->qcount, qcap, w.skeys, (unsigned long long *)nullptr, w.qn, h->xt,
                            h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
     CRH_HIP(hipGetLastError());
     h->stats.rows += h->count;
@@ -634,6 +640,7 @@ int crh_index_destroy(crh_index *h)
         dev_free(w.qfrag8);
         dev_free(w.qpar);
         dev_free(w.qlo);
+        dev_free(w.skeys2);
     }
     dev_free(h->x8);
     dev_free(h->srow);
@@ -1032,6 +1039,12 @@ int crh_debug_fused_stamps(unsigned long long *out)
 {
     CRH_HIP(hipDeviceSynchronize());
     CRH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 256 * 24));
+    return CRH_OK;
+}
+int crh_debug_select_stamps(unsigned long long *out)
+{
+    CRH_HIP(hipDeviceSynchronize());
+    CRH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_select_stamps), sizeof(unsigned long long) * 64 * 8));
     return CRH_OK;
 }
 #endif

@@ -43,6 +43,8 @@ struct SearchStatus {
     unsigned int bar_timeout;    // set when one of those waits gave up (a workgroup never became resident): results are void
     unsigned int pad_;
     unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
+    unsigned int qsurv[kMaxQ];    // k_select split over several workgroups per query: survivors published so far ...
+    unsigned int qdone[kMaxQ];    // ... and workgroups that have published (the last one ranks)
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -835,6 +837,26 @@ __device__ KeyT wg_kth_largest(Get get, unsigned int n, unsigned int k, unsigned
     return prefix;
 }
 
+// f(key, i) for every i = tid, tid + NT, ... < n, the keys fetched EIGHT at a time: when get() reads global memory (tens of
+// thousands of candidates per query behind the int8 scan) a sweep is otherwise a chain of dependent round trips, n / NT deep.
+template <int NT, typename Get, typename F>
+__device__ __forceinline__ void for_each_key(Get get, unsigned int n, F f)
+{
+    for (unsigned int base = threadIdx.x; base < n; base += NT * 8) {
+        uint32_t key[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int i = base + j * NT;
+            key[j] = i < n ? get(i) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int i = base + j * NT;
+            if (i < n) f(key[j], i);
+        }
+    }
+}
+
 // k-th largest (1-based) of n u32 keys in TWO steps instead of four radix passes.  The keys of one query -- candidate scores
 // above a common threshold, or tile maxima of one query -- sit in a narrow band of the u32 range, so an order-preserving LINEAR
 // bucketing of [lo, hi] into NB buckets (lo / hi: smallest / largest key above `floor_key`, which takes the -inf padding out of
@@ -853,15 +875,14 @@ __device__ uint32_t wg_kth_largest_fast(Get get, unsigned int n, unsigned int k,
     // 1. range of the keys above the floor, and how many sit at or below it
     uint32_t lo = 0xffffffffu, hi = 0u;
     unsigned int below = 0u;
-    for (unsigned int i = tid; i < n; i += NT) {
-        const uint32_t key = get(i);
+    for_each_key<NT>(get, n, [&](uint32_t key, unsigned int) {
         if (key > floor_key) {
             lo = key < lo ? key : lo;
             hi = key > hi ? key : hi;
         } else {
             ++below;
         }
-    }
+    });
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const uint32_t ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
@@ -897,10 +918,9 @@ __device__ uint32_t wg_kth_largest_fast(Get get, unsigned int n, unsigned int k,
         return b < (unsigned int)NB ? b : (unsigned int)NB - 1u;
     };
     // 2. one histogram pass
-    for (unsigned int i = tid; i < n; i += NT) {
-        const uint32_t key = get(i);
+    for_each_key<NT>(get, n, [&](uint32_t key, unsigned int) {
         if (key > floor_key) atomicAdd(&hist[bucket(key)], 1u);
-    }
+    });
     __syncthreads();
     // 3. which bucket holds the k-th: thread t owns bucket NB-1-t (descending), suffix sums by wave scan + wave totals
     unsigned int mine = tid < NB ? hist[NB - 1 - tid] : 0u, incl = mine;
@@ -926,10 +946,9 @@ __device__ uint32_t wg_kth_largest_fast(Get get, unsigned int n, unsigned int k,
         return wg_kth_largest<uint32_t, NT>(get, n, k, radix_hist, bcast);
     }
     // 4. the bucket's members, then the rem-th largest of them by counting (equal keys allowed)
-    for (unsigned int i = tid; i < n; i += NT) {
-        const uint32_t key = get(i);
+    for_each_key<NT>(get, n, [&](uint32_t key, unsigned int) {
         if (key > floor_key && bucket(key) == bsel) list[atomicAdd(&ctl[4], 1u)] = key;
-    }
+    });
     __syncthreads();
     if ((unsigned int)tid < pop) {
         const uint32_t key = list[tid];
@@ -1017,12 +1036,18 @@ __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int ex
 // Phase clocks of a MEASUREMENT build (-DCRH_FUSED_STAMPS, tools/fused_stamps.py); in the product CRH_STAMP is nothing.
 #ifdef CRH_FUSED_STAMPS
 __device__ unsigned long long g_fused_stamps[256 * 8 + 256 * 16];
+__device__ unsigned long long g_select_stamps[64 * 8];
+#define CRH_SEL_STAMP(n)                                                                          \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_select_stamps[blockIdx.x * 8 + (n)] = wall_clock64(); \
+    } while (0)
 #define CRH_STAMP(n)                                                                                      \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 256) g_fused_stamps[blockIdx.x * 8 + (n)] = wall_clock64();  \
     } while (0)
 #else
 #define CRH_STAMP(n) ((void)0)
+#define CRH_SEL_STAMP(n) ((void)0)
 #endif
 
 template <int KSTEPS, int WAVES, int RING, int QB = 2>
@@ -1323,108 +1348,14 @@ __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf3
     return acc;
 }
 
-// ------------------------------------------------------------------ final selection
-
-// One workgroup per query.  From the query's candidate list (approximate MFMA scores):
-//   1. a_k   = k-th largest approximate score;
-//   2. keep every candidate with approx >= a_k - margin  (margin >= 2*max|approx - canonical|, so
-//      the canonical top-k is inside);
-//   3. re-score the survivors canonically, key = (ord(score) << 32) | ~row;
-//   4. exact top-k of the keys (descending score, ascending row), written with row_base added.
-// I8 (the candidates come from k_scan_i8, crh_i8.hpp): an entry's score is the UPPER end of the row's interval and qlo holds the
-// lower ends; step 1 takes the k-th largest LOWER end, step 2 keeps every candidate whose UPPER end reaches it, no margin.
-template <bool F32, bool I8 = false>
-__global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist, const float *__restrict__ qlo,
-                                                  const unsigned int *__restrict__ qcount,
-                                                  int qcap, unsigned long long *__restrict__ skeys,
-                                                  const float *__restrict__ qn, const u32x4 *__restrict__ xt,
-                                                  const float *__restrict__ xf32, int dim, int ksteps, int k,
-                                                  float margin, int64_t row_base, float *__restrict__ out_scores,
-                                                  int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
+// Step 4 of k_select: exact top-k of Ms unique keys (descending score, ascending row), written with row_base added.  The keys
+// sit in LDS (`lkeys`, when in_lds) or in global memory (`sk`).
+template <int NT>
+__device__ void select_tail(const unsigned long long *sk, unsigned int Ms, bool in_lds, unsigned long long *lkeys, unsigned long long *sortbuf,
+                            unsigned int *hist, unsigned int *bcast, unsigned int *scount_p, int k, int64_t row_base, float *os, int64_t *orow)
 {
-    constexpr int NT = 1024;
-    constexpr unsigned int LCAP = 2048;   // survivors kept in LDS (the normal case: ~k + a few)
-    constexpr unsigned int SCAP = 16384;  // candidate scores kept in LDS for the selection passes (64 KB)
-    __shared__ uint32_t lscore[SCAP];
-    __shared__ float qv[2048];
-    __shared__ unsigned long long lkeys[LCAP];
-    __shared__ unsigned long long sortbuf[CRH_MAX_K];
-    __shared__ unsigned int hist[(NT / 64) * 256];
-    __shared__ unsigned int bcast[2];
-    __shared__ unsigned int scount;
-    __shared__ unsigned int fast[1024 + 256 + 2 * (NT / 64) + 8];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const unsigned int mtrue = qcount[q];
-    const unsigned int M = mtrue < (unsigned int)qcap ? mtrue : (unsigned int)qcap;
-    if (tid == 0) {
-        atomicMax(&status->max_qcount, mtrue);
-        atomicAdd(&status->candidates, (unsigned long long)mtrue);
-        if (mtrue > (unsigned int)qcap) atomicAdd(&status->q_overflow, 1u);
-        scount = 0u;
-    }
-    for (int i = tid; i < dim; i += NT) qv[i] = qn[(size_t)q * dim + i];
-    float *os = out_scores + (size_t)q * k;
-    int64_t *orow = out_rows + (size_t)q * k;
-    if (M == 0u) {
-        for (int i = tid; i < k; i += NT) {
-            os[i] = -INFINITY;
-            orow[i] = -1;
-        }
-        return;
-    }
-    const u32x2 *ql = qlist + (size_t)q * qcap;
-    const float *qlq = I8 ? qlo + (size_t)q * qcap : nullptr;
-    unsigned long long *sk = skeys + (size_t)q * qcap;
-    auto first_key = [&](unsigned int i) { return I8 ? ord_f32(qlq[i]) : ord_f32(bits_f32(ql[i].x)); };   // what step 1 ranks
-    __syncthreads();
-
-    // the four radix passes and the survivor cut all re-read the candidate scores: stage them in LDS once (one batch of
-    // independent loads) instead of paying an L2 round trip per element per pass
-    const unsigned int kk = (unsigned int)k < M ? (unsigned int)k : M;
-    const bool staged = M <= SCAP;
-    if (staged) {
-#pragma unroll 4
-        for (unsigned int i = tid; i < M; i += NT) lscore[i] = first_key(i);
-        __syncthreads();
-    }
-    const uint32_t akey = staged ? wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return lscore[i]; }, M, kk, 0u, fast, hist, bcast)
-                          : I8   ? wg_kth_largest_fast<NT, 1024, 256>(first_key, M, kk, 0u, fast, hist, bcast)   // (tens of thousands of candidates)
-                                 : wg_kth_largest<uint32_t, NT>(first_key, M, kk, hist, bcast);
-    const uint32_t lower_key = I8 ? akey : ord_f32(unord_f32(akey) - margin);
-
-    for (unsigned int i0 = 0; i0 < M; i0 += NT) {     // (whole waves take part in every round: the compaction uses ballots)
-        const unsigned int i = i0 + tid;
-        const uint32_t sc = i < M ? ((staged && !I8) ? lscore[i] : ord_f32(bits_f32(ql[i].x))) : 0u;
-        const bool keep = i < M && sc >= lower_key;
-        const unsigned long long bm = __ballot(keep);   // one LDS atomic per wave, not one per survivor
-        unsigned int base = 0u;
-        if ((tid & 63) == 0 && bm != 0ull) base = atomicAdd(&scount, (unsigned int)__popcll(bm));
-        base = __shfl(base, 0);
-        if (keep) {
-            const unsigned int p = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bm, 0u));
-            const unsigned int row = ql[i].y;
-            if (p < LCAP) lkeys[p] = (unsigned long long)row;
-            sk[p] = (unsigned long long)row;
-        }
-    }
-    __syncthreads();
-    const unsigned int Ms = scount;
-    const bool in_lds = Ms <= LCAP;
-    // Canonical re-score: one thread per survivor walks its row (96 pieces of 16 bytes, fetched 16 at a time, consumed in index
-    // order).  Splitting a row over 2 / 4 / 8 lanes (all lanes fetch at once, the running sum handed from lane to lane in index
-    // order, products formed ahead of the ordered additions) returns the same bits with a quarter of the memory round trips --
-    // and took 65 / 65 / 18 us LONGER per batch (tools: lib variants, 10M rows, 50 steps): every wave of the workgroup then
-    // executes the whole ordered chain for a handful of rows, where here three waves do.
-    for (unsigned int p = tid; p < Ms; p += NT) {
-        const uint32_t row = (uint32_t)(in_lds ? lkeys[p] : sk[p]);
-        const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv);
-        const unsigned long long key = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
-        if (in_lds)
-            lkeys[p] = key;
-        else
-            sk[p] = key;
-    }
-    __syncthreads();
+    const int tid = threadIdx.x;
+    unsigned int &scount = *scount_p;
     const unsigned int k2 = (unsigned int)k < Ms ? (unsigned int)k : Ms;
 
     if (in_lds) {
@@ -1443,7 +1374,7 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
             os[i] = -INFINITY;
             orow[i] = -1;
         }
-        return;
+                return;
     }
 
     // general path (more survivors than LDS holds: massive ties / duplicates): 64-bit radix select + sort of the top k
@@ -1472,6 +1403,175 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
             orow[i] = -1;
         }
     }
+}
+
+// ------------------------------------------------------------------ final selection
+
+// One workgroup per query.  From the query's candidate list (approximate MFMA scores):
+//   1. a_k   = k-th largest approximate score;
+//   2. keep every candidate with approx >= a_k - margin  (margin >= 2*max|approx - canonical|, so
+//      the canonical top-k is inside);
+//   3. re-score the survivors canonically, key = (ord(score) << 32) | ~row;
+//   4. exact top-k of the keys (descending score, ascending row), written with row_base added.
+// I8 (the candidates come from k_scan_i8, crh_i8.hpp): an entry's score is the UPPER end of the row's interval and qlo holds the
+// lower ends; step 1 takes the k-th largest LOWER end, step 2 keeps every candidate whose UPPER end reaches it, no margin.
+// With tens of thousands of candidates the ~800 survivors of a query are re-scored by gridDim.y workgroups (their rows are 96
+// scattered 16-byte pieces each: one CU's L1 took 215 us for them, stamps of round 3): every workgroup finds the same cut, takes
+// the survivors whose candidate index is its own modulo gridDim.y, publishes their keys in `fin`, and the LAST one to finish
+// ranks them all (no workgroup waits for another).
+template <bool F32, bool I8 = false>
+__global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist, const float *__restrict__ qlo,
+                                                  const unsigned int *__restrict__ qcount,
+                                                  int qcap, unsigned long long *__restrict__ skeys, unsigned long long *__restrict__ fin,
+                                                  const float *__restrict__ qn, const u32x4 *__restrict__ xt,
+                                                  const float *__restrict__ xf32, int dim, int ksteps, int k,
+                                                  float margin, int64_t row_base, float *__restrict__ out_scores,
+                                                  int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
+{
+    constexpr int NT = 1024;
+    constexpr unsigned int LCAP = 2048;   // survivors kept in LDS (the normal case: ~k + a few)
+    constexpr unsigned int SCAP = 16384;  // candidate scores kept in LDS for the selection passes (64 KB)
+    __shared__ uint32_t lscore[SCAP];
+    __shared__ float qv[2048];
+    __shared__ unsigned long long lkeys[LCAP];
+    __shared__ unsigned long long sortbuf[CRH_MAX_K];
+    __shared__ unsigned int hist[(NT / 64) * 256];
+    __shared__ unsigned int bcast[2];
+    __shared__ unsigned int scount;
+    __shared__ unsigned int fast[1024 + 256 + 2 * (NT / 64) + 8];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned int mtrue = qcount[q];
+    const unsigned int M = mtrue < (unsigned int)qcap ? mtrue : (unsigned int)qcap;
+    const bool split = I8 && gridDim.y > 1 && M > 4096u;
+    if (!split && blockIdx.y != 0) return;
+    const unsigned int parts = split ? gridDim.y : 1u, part = split ? blockIdx.y : 0u;
+    if (tid == 0) {
+        if (blockIdx.y == 0) {
+            atomicMax(&status->max_qcount, mtrue);
+            atomicAdd(&status->candidates, (unsigned long long)mtrue);
+            if (mtrue > (unsigned int)qcap) atomicAdd(&status->q_overflow, 1u);
+        }
+        scount = 0u;
+    }
+    for (int i = tid; i < dim; i += NT) qv[i] = qn[(size_t)q * dim + i];
+    float *os = out_scores + (size_t)q * k;
+    int64_t *orow = out_rows + (size_t)q * k;
+    if (M == 0u) {
+        for (int i = tid; i < k; i += NT) {
+            os[i] = -INFINITY;
+            orow[i] = -1;
+        }
+        return;
+    }
+    CRH_SEL_STAMP(0);
+    const u32x2 *ql = qlist + (size_t)q * qcap;
+    const float *qlq = I8 ? qlo + (size_t)q * qcap : nullptr;
+    unsigned long long *sk = skeys + (size_t)q * qcap + (size_t)part * ((unsigned int)qcap / parts);   // (a part keeps <= ceil(M / parts) rows)
+    auto first_key = [&](unsigned int i) { return I8 ? ord_f32(qlq[i]) : ord_f32(bits_f32(ql[i].x)); };   // what step 1 ranks
+    __syncthreads();
+
+    // the four radix passes and the survivor cut all re-read the candidate scores: stage them in LDS once (one batch of
+    // independent loads) instead of paying an L2 round trip per element per pass
+    const unsigned int kk = (unsigned int)k < M ? (unsigned int)k : M;
+    const bool staged = M <= SCAP;
+    if (staged) {
+#pragma unroll 4
+        for (unsigned int i = tid; i < M; i += NT) lscore[i] = first_key(i);
+        __syncthreads();
+    }
+    const uint32_t akey = staged ? wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return lscore[i]; }, M, kk, 0u, fast, hist, bcast)
+                          : I8   ? wg_kth_largest_fast<NT, 1024, 256>(first_key, M, kk, 0u, fast, hist, bcast)   // (tens of thousands of candidates)
+                                 : wg_kth_largest<uint32_t, NT>(first_key, M, kk, hist, bcast);
+    const uint32_t lower_key = I8 ? akey : ord_f32(unord_f32(akey) - margin);
+    CRH_SEL_STAMP(1);
+
+    // (whole waves take part in every round: the compaction uses ballots; the scores of eight rounds are fetched together)
+    for (unsigned int i0 = 0; i0 < M; i0 += NT * 8) {
+        uint32_t sc8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int i = i0 + j * NT + tid;
+            sc8[j] = i < M ? ((staged && !I8) ? lscore[i] : ord_f32(bits_f32(ql[i].x))) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i0 + j * NT >= M) break;                   // (workgroup-uniform)
+            const unsigned int i = i0 + j * NT + tid;
+            const bool keep = i < M && sc8[j] >= lower_key && (!split || (i % parts) == part);
+            const unsigned long long bm = __ballot(keep);   // one LDS atomic per wave, not one per survivor
+            unsigned int base = 0u;
+            if ((tid & 63) == 0 && bm != 0ull) base = atomicAdd(&scount, (unsigned int)__popcll(bm));
+            base = __shfl(base, 0);
+            if (keep) {
+                const unsigned int p = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bm, 0u));
+                const unsigned int row = ql[i].y;
+                if (p < LCAP) lkeys[p] = (unsigned long long)row;
+                sk[p] = (unsigned long long)row;
+            }
+        }
+    }
+    __syncthreads();
+    CRH_SEL_STAMP(2);
+    const unsigned int Ms = scount;
+    if (tid == 0 && blockIdx.x < 64) {
+#ifdef CRH_FUSED_STAMPS
+        g_select_stamps[blockIdx.x * 8 + 6] = Ms;
+        g_select_stamps[blockIdx.x * 8 + 7] = M;
+#endif
+    }
+    const bool in_lds = Ms <= LCAP;
+    // Canonical re-score: one thread per survivor walks its row (96 pieces of 16 bytes, fetched 16 at a time, consumed in index
+    // order).  Splitting a row over 2 / 4 / 8 lanes (all lanes fetch at once, the running sum handed from lane to lane in index
+    // order, products formed ahead of the ordered additions) returns the same bits with a quarter of the memory round trips --
+    // and took 65 / 65 / 18 us LONGER per batch (tools: lib variants, 10M rows, 50 steps): every wave of the workgroup then
+    // executes the whole ordered chain for a handful of rows, where here three waves do.
+    for (unsigned int p = tid; p < Ms; p += NT) {
+        const uint32_t row = (uint32_t)(in_lds ? lkeys[p] : sk[p]);
+        const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv);
+        const unsigned long long key = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+        if (in_lds)
+            lkeys[p] = key;
+        else
+            sk[p] = key;
+    }
+    __syncthreads();
+    CRH_SEL_STAMP(3);
+    if (split) {
+        // publish this part's keys; the workgroup that arrives last takes all of them
+        if (tid == 0) bcast[0] = atomicAdd(&status->qsurv[q], Ms);
+        __syncthreads();
+        unsigned long long *fq = fin + (size_t)q * qcap;
+        const unsigned int gbase = bcast[0];
+        for (unsigned int p = tid; p < Ms; p += NT) fq[gbase + p] = in_lds ? lkeys[p] : sk[p];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int arrived = __hip_atomic_fetch_add(&status->qdone[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned int total = 0u;
+            if (arrived == parts - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                total = __hip_atomic_load(&status->qsurv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bcast[0] = arrived == parts - 1u ? 1u : 0u;
+            bcast[1] = total;
+        }
+        __syncthreads();
+        if (bcast[0] == 0u) return;
+        const unsigned int Mt = bcast[1];
+        __syncthreads();
+        const bool all_lds = Mt <= LCAP;
+        if (all_lds) {
+            for (unsigned int p = tid; p < Mt; p += NT) lkeys[p] = fq[p];
+            __syncthreads();
+        }
+        select_tail<NT>(fq, Mt, all_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
+        CRH_SEL_STAMP(4);
+        return;
+    }
+    select_tail<NT>(sk, Ms, in_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
+    CRH_SEL_STAMP(4);
 }
 
 // ------------------------------------------------------------------ cross-shard merge

@@ -21,6 +21,8 @@ qd = torch.randn((B, D), generator=gen, device=dev)
 s = torch.empty((B, K), dtype=torch.float32, device=dev); r = torch.empty((B, K), dtype=torch.int64, device=dev)
 L = ffi.lib()
 L.crh_debug_fused_stamps.argtypes = [C.c_void_p]; L.crh_debug_fused_stamps.restype = C.c_int
+L.crh_debug_select_stamps.argtypes = [C.c_void_p]; L.crh_debug_select_stamps.restype = C.c_int
+sel = []
 acc = []
 wacc = []
 for it in range(12):
@@ -31,6 +33,9 @@ for it in range(12):
     if it >= 2:
         acc.append(buf[:2048].reshape(256, 8).astype(np.int64))
         wacc.append(buf[2048:].reshape(256, 16).astype(np.int64))
+        sb = np.zeros(64 * 8, np.uint64)
+        assert L.crh_debug_select_stamps(sb.ctypes.data) == 0
+        sel.append(sb.reshape(64, 8).astype(np.int64))
 names = ["query image", "sample tile", "wait A", "threshold", "wait B", "main loop"]
 a = np.stack(acc)                                    # [runs, wg, stamp]
 t0 = a[:, :, 0].min(axis=1, keepdims=True)           # the first workgroup's entry
@@ -55,3 +60,12 @@ for x in range(8):
     print(f"  xcd {x}: {v.min(axis=1).mean():7.0f} {np.median(v, axis=1).mean():7.0f} {v.max(axis=1).mean():7.0f}")
 qs_ = np.percentile(e, [0, 5, 25, 50, 75, 95, 100], axis=1).mean(axis=1)
 print("  all workgroups, percentiles 0/5/25/50/75/95/100: " + " ".join(f"{v:.0f}" for v in qs_))
+if (a[:, :, 7] > 0).all():
+    v = (a[:, :, 7] - a[:, :, 6]) / 100.0
+    print(f"hand-over of the candidates after the main loop (us): median {np.median(v):.1f}, max {v.max(axis=1).mean():.1f}; kernel end {((a[:, :, 7] - t0) / 100.0).max(axis=1).mean():.0f}")
+sl = np.stack(sel)                                   # [runs, query, stamp]; 6 = survivors, 7 = candidates
+ph = np.diff(sl[:, :, :5], axis=2) / 100.0
+print("k_select per query workgroup (us): k-th largest / survivor sweep / canonical re-score / ranking -- median, max over queries; mean over runs")
+for i, n in enumerate(["k-th largest", "survivor sweep", "re-score", "ranking"]):
+    print(f"  {n:15s} {np.median(ph[:, :, i], axis=1).mean():8.1f} {ph[:, :, i].max(axis=1).mean():8.1f}")
+print(f"  candidates per query: median {np.median(sl[:, :, 7]):.0f}, max {sl[:, :, 7].max()};  survivors: median {np.median(sl[:, :, 6]):.0f}, max {sl[:, :, 6].max()}")
