@@ -563,3 +563,101 @@ def test_fused_scan_that_times_out_is_run_again_in_the_three_kernel_form(gpu):
     assert idx.stats()["fallback_used"] == 0
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
     idx.close()
+
+
+# ---------------------------------------------------------------------------------------------- int8 nomination (crh_i8.hpp)
+
+def _exact(idx, x, q, k, bf16, alive=None):
+    s, r = idx.search(q, k)
+    es, er = orc.cosine_search(x, q, k, bf16=bf16, alive=alive)
+    assert np.array_equal(r, er), "ids differ from the oracle"
+    assert np.array_equal(s.view(np.uint32), es.view(np.uint32)), "score bits differ from the oracle"
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_int8_nomination_rows_with_outlier_elements_zero_rows_and_tiny_rows(gpu, bf16):
+    """The interval of a row scales with max|x| of THAT row: rows dominated by one element (coarse int8 steps everywhere else),
+    all-zero rows and rows of tiny norm (normalised on insert) sit among ordinary rows; queries with an outlier element too."""
+    ffi = _ffi()
+    rng = np.random.default_rng(31)
+    n = 60_000
+    x = rng.standard_normal((n, D), dtype=np.float32)
+    spike = rng.choice(n, 4000, replace=False)
+    x[spike, rng.integers(0, D, 4000)] += rng.choice([-1.0, 1.0], 4000).astype(np.float32) * 40.0   # one element ~ the whole norm
+    x[rng.choice(n, 300, replace=False)] = 0.0
+    x[rng.choice(n, 300, replace=False)] *= 1e-20
+    q = rng.standard_normal((64, D), dtype=np.float32)
+    q[:8, 5] += 30.0
+    q[8] = 0.0
+    idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n)
+    idx.append(x)
+    _exact(idx, x, q, 100, bf16)
+    assert idx.stats()["fallback_used"] & 3 == 0
+    idx.close()
+
+
+def test_int8_nomination_follows_appends_tombstones_and_compaction(gpu):
+    """The int8 copy is derived lazily: rows appended after a search (into a partly filled tile and into new tiles), after a
+    reserve that reallocates, and rows moved by compaction are requantised before the next scan."""
+    ffi = _ffi()
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((50_021, D), dtype=np.float32)
+    q = rng.standard_normal((33, D), dtype=np.float32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=20_000)
+    idx.append(x[:10_007])
+    _exact(idx, x[:10_007], q, 50, True)
+    idx.append(x[10_007:19_999])                      # fills the partial tile, stays inside the capacity
+    _exact(idx, x[:19_999], q, 50, True)
+    idx.reserve(60_000)                               # reallocation: the copy is rebuilt
+    idx.append(x[19_999:])
+    _exact(idx, x, q, 50, True)
+    dead = rng.choice(len(x), 20_000, replace=False)
+    idx.tombstone(dead)
+    alive = np.ones(len(x), np.uint8)
+    alive[dead] = 0
+    _exact(idx, x, q, 50, True, alive=alive)
+    o2n = idx.compact()
+    keep = np.flatnonzero(alive)
+    assert np.array_equal(o2n[keep], np.arange(len(keep)))
+    _exact(idx, x[keep], q, 50, True)
+    assert idx.stats()["fallback_used"] == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_int8_nomination_with_masses_of_identical_rows(gpu, bf16):
+    """200 000 copies of three rows: every candidate's interval is the same, all of them survive the cut (far more than the
+    selection keeps in LDS), the selection is split over several workgroups per query and the last one ranks from global memory;
+    ties go to the lower row."""
+    ffi = _ffi()
+    rng = np.random.default_rng(33)
+    base = rng.standard_normal((3, D), dtype=np.float32)
+    n = 200_000
+    x = base[rng.integers(0, 3, n)]
+    x[::1000] = rng.standard_normal((len(x[::1000]), D), dtype=np.float32)
+    q = np.concatenate([base + 0.01 * rng.standard_normal((3, D), dtype=np.float32), rng.standard_normal((5, D), dtype=np.float32)])
+    idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n)
+    idx.append(x)
+    _exact(idx, x, q, 100, bf16)
+    idx.close()
+
+
+def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
+    """Intervals too wide for the buffers (here: buffers made tiny) -> the batch is run again on the bf16 scan (bit 2 of
+    fallback_used), which regrows ITS buffers (bit 0); after three such batches the copy is left unused."""
+    ffi = _ffi()
+    rng = np.random.default_rng(34)
+    x = rng.standard_normal((40_000, D), dtype=np.float32)
+    q = rng.standard_normal((64, D), dtype=np.float32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=len(x))
+    idx.append(x)
+    _exact(idx, x, q, 20, True)
+    assert idx.stats()["fallback_used"] == 0
+    idx.set_tuning(force_fallback=1)
+    for _ in range(3):
+        _exact(idx, x, q, 20, True)
+        assert idx.stats()["fallback_used"] & 4
+    idx.set_tuning(force_fallback=0)
+    _exact(idx, x, q, 20, True)
+    assert idx.stats()["fallback_used"] == 0          # three strikes: this index now scans its bf16 rows
+    idx.close()
