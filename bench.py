@@ -38,7 +38,7 @@ _T0 = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-ALL_LEGS = ("filtered", "wide", "config5", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
+ALL_LEGS = ("filtered", "scan_bf16", "wide", "config5", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
 
 
 def log(msg: str) -> None:
@@ -297,22 +297,27 @@ def timed_search(torch, idx, qd, K, filters, steps, warmup, stream):
             "scan_launches": launches, "stats": idx.stats(), "scores": out_s[last], "rows": out_r[last]}
 
 
-def scan_kernel_name(D, B=64):
-    """The dominant kernel of a <= 64-query batch as the library launches it (crh_index.hip, enqueue_batch): the one-launch
-    scan (sample tiles + thresholds + every other tile) unless it is switched off or the width has no instance."""
-    ks = D // 16
+def scan_kernel_name(D, mode):
+    """The dominant kernel of a <= 64-query batch, by the nomination mode the index reports (crh_index_get_nomination):
+    2 = the one-launch scan over the int8 copy, 1 = the one-launch scan over the bf16 tiles, 0 = the three-launch form."""
     qb = 1 if D == 1536 else 2
-    if os.environ.get("CODERAG_HIP_FUSED_SCAN", "1")[:1] != "0" and ks in (24, 48, 96):
-        return f"k_scan_fused<{ks},16,8,{qb}>"
-    return f"k_scan<{ks},1,16,8,{qb}>"
+    if mode == 2:
+        return f"k_scan_i8<{D // 32},8,8,{qb}>"
+    if mode == 1:
+        return f"k_scan_fused<{D // 16},16,8,{qb}>"
+    return f"k_scan<{D // 16},1,16,8,{qb}>"
 
 
-def scan_roofline(rows, D, scan_ms, launches, kernel=None):
-    kernel = kernel or scan_kernel_name(D)
-    alg = float(rows) * D * 2          # the scan always streams the bf16 tiled copy (the one-launch form: exactly once)
+def scan_roofline(rows, D, scan_ms, launches, mode):
+    """Algorithmic bytes of one pass: the int8 copy is 1 byte per element + one f32 scale per row, the bf16 tiles 2 bytes per
+    element; every mode reads its copy of the corpus once (the three-launch form's seed scan is outside the timed kernel)."""
+    alg = float(rows) * (D + 4) if mode == 2 else float(rows) * D * 2
     ach = alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "kernel": kernel, "kernel_ms": scan_ms, "launches": launches, "algorithmic_bytes_per_launch": alg}
+            "kernel": scan_kernel_name(D, mode), "kernel_ms": scan_ms, "launches": launches, "algorithmic_bytes_per_launch": alg,
+            "bytes_per_row": (D + 4) if mode == 2 else D * 2,
+            "nomination": ("int8 copy of the rows (i8 MFMA, exact integer dot, per-row error intervals)" if mode == 2 else "bf16 tiles (bf16 MFMA)")
+                          + "; every returned id and score: canonical f32 arithmetic on the stored rows"}
 
 
 def subsample_parity(np, ffi, orc, head, head_codes, qs, K, dtype, device, filters=None):
@@ -370,7 +375,7 @@ def run(args, json_fd) -> None:
     if args.no_cpu_baseline or world > 1:
         legs -= {"cpu"}
     if world > 1:
-        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "wide"}      # one-GPU verification legs
+        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "scan_bf16", "wide"}      # one-GPU verification legs
 
     D, N, B, K = 768, args.rows, args.queries, args.k
     if args.scaling == "strong":
@@ -437,6 +442,8 @@ def run(args, json_fd) -> None:
     stats = idx.stats()
     last = (args.steps - 1) % nslots
     headline_rows = out_r[last].clone()          # this rank's local top-k of the last timed step (global row ids)
+    headline_scores = out_s[last].clone()
+    nom_mode = idx.nomination()                  # how the timed batches were nominated (2: int8 copy, 1 / 0: bf16 tiles)
 
     # ---- what actually took part in the exchange (N>1): distinct ranks seen through a real all-gather, per-rank step times,
     # and the merged list against a sort of the gathered lists (score descending, lower global row first)
@@ -479,14 +486,14 @@ def run(args, json_fd) -> None:
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_scan.json")))
-        if int(pmc.get("rows", -1)) == N and pmc.get("kernel") == scan_kernel_name(D):
+        if int(pmc.get("rows", -1)) == N and pmc.get("kernel") == scan_kernel_name(D, nom_mode):
             traffic = float(pmc["hbm_read_bytes_corrected"]) + float(pmc["hbm_write_bytes"])
     except (OSError, ValueError, KeyError):
         pass
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt * (N / 1e7)
     scan_ms = scan_ms_total / max(1, scan_launches)
-    roof = scan_roofline(N, D, scan_ms, scan_launches)
+    roof = scan_roofline(N, D, scan_ms, scan_launches, nom_mode)
     roof["traffic"] = traffic
     roof["traffic_source"] = "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None
     out = {
@@ -501,8 +508,11 @@ def run(args, json_fd) -> None:
                                + (", all-gather + merge of per-GPU top-k over RCCL" if world > 1 else "")
                                + (f" ({args.rows} rows in total, strong scaling)" if args.scaling == "strong" else ""),
                    "rows_per_gpu": N, "dim": D, "batch": B, "k": K, "parallelism": f"row-shard x{world}",
-                   "precision": ("bf16 corpus and queries on MFMA, f32 accumulate, canonical f32 re-score of the survivors" if args.dtype == "bf16"
-                                 else "f32 store: bf16 MFMA scan nominates, f32 canonical re-score decides")},
+                   "precision": ("bf16 corpus; rows nominated from " + ("an int8 copy (i8 MFMA, exact integer dot, rigorous per-row error intervals)"
+                                                                              if nom_mode == 2 else "the bf16 tiles (bf16 MFMA, f32 accumulate)")
+                                 + ", canonical f32 re-score of the survivors on the bf16 rows decides every id and score" if args.dtype == "bf16"
+                                 else "f32 store: the scan nominates, f32 canonical re-score decides"),
+                   "hbm_resident_bytes_per_row": D * (2 if args.dtype == "bf16" else 6) + (D + 4 if nom_mode == 2 else 0)},
         "roofline": roof,
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
@@ -537,11 +547,29 @@ def run(args, json_fd) -> None:
         res = {"workload": f"{N}x{D} {args.dtype}, batch-{B} top-{K}, filter language == code 1 of 3 (uniform)",
                "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7), "unit": out["unit"], "ms_per_step": r["ms_per_step"],
                "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
-               "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"]), "search_stats": r["stats"]}
+               "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], idx.nomination()), "search_stats": r["stats"]}
         if orc is not None:
             res["parity"] = subsample_parity(np, ffi, orc, head, head_codes, qs, K, dtype, local_rank, filters=[(0, 1)])
         log(f"filtered: {r['ms_per_step']:.3f} ms/step")
         return res
+
+    def scan_bf16_leg():
+        """The headline batch with the int8 copy switched off: the one-launch scan over the bf16 tiles (rounds 1-2's path, and
+        what an index falls back to).  Same rows, same score bits."""
+        if nom_mode != ffi.NOMINATE_INT8:
+            return None
+        idx.set_nomination(ffi.NOMINATE_BF16)
+        try:
+            r = timed_search(torch, idx, qd, K, None, args.sub_steps, 3, stream)
+            mode = idx.nomination()
+        finally:
+            idx.set_nomination(ffi.NOMINATE_INT8)
+        same = bool(torch.equal(r["rows"], headline_rows - row_base) and torch.equal(r["scores"].view(torch.int32), headline_scores.view(torch.int32)))
+        log(f"scan_bf16: {r['ms_per_step']:.3f} ms/step")
+        return {"workload": f"{N}x{D} {args.dtype}, batch-{B} top-{K}, nominated from the bf16 tiles", "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7),
+                "unit": out["unit"], "ms_per_step": r["ms_per_step"], "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
+                "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode), "search_stats": r["stats"],
+                "identical_to_headline": same}
 
     def wide_leg():
         """One search call with 512 queries: two passes of k_scan_wide (256 queries share a corpus pass, query fragments in
@@ -576,6 +604,7 @@ def run(args, json_fd) -> None:
         return res
 
     leg("filtered", filtered_leg)
+    leg("scan_bf16", scan_bf16_leg)
     leg("wide", wide_leg)
     leg("config5", config5_leg, np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, args.sub_steps, stream)
     idx.close()
@@ -591,8 +620,8 @@ def run(args, json_fd) -> None:
             res = {"workload": f"{N}x{D} f32 store (bf16 MFMA scan nominates, f32 master re-scores), batch-{B} top-{K}",
                    "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7), "unit": out["unit"], "ms_per_step": r["ms_per_step"],
                    "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
-                   "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"]), "search_stats": r["stats"],
-                   "hbm_resident_bytes": float(N) * D * 6,
+                   "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], f32.nomination()), "search_stats": r["stats"],
+                   "hbm_resident_bytes": float(N) * D * (7 if f32.nomination() == 2 else 6),
                    "recall_at_k_of_the_bf16_store_vs_this_store_full_corpus": full}
             if orc is not None:
                 res["parity"] = subsample_parity(np, ffi, orc, h32, hc32, qs, K, ffi.DTYPE_F32, local_rank)
@@ -738,7 +767,7 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
             "value": world * B / wall * (N / 1e7), "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7), re-ranked",
             "ms_per_step": wall * 1e3, "steps": steps, "rerank_ms_per_batch": rerank * 1e3,
             "host_hybrid_ranker_ms_per_batch": t_host * 1e3, "survivors": survivors,
-            "roofline": scan_roofline(N, 768, scan, launches),
+            "roofline": scan_roofline(N, 768, scan, launches, idx.nomination()),
             "store_sharded": sharded,
             "parity": {"identical_to_host_hybrid_ranker": bool(ok), "queries": B,
                        "what": "survivors, order, f64 final scores, the four signals and the source label of every query"}}

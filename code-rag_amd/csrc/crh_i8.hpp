@@ -207,7 +207,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const int gw = blockIdx.x * WAVES + wave;
     u32x4 *mylist = wave_lists + (size_t)gw * wave_cap;
     unsigned int wcnt = 0;
-    auto tile_ptr = [&](int64_t tile) { return x8 + (size_t)tile * (KS8 * 64) + lane; };
+    // A tile's address is wave-uniform: loads take it as a SCALAR base plus the lane's byte offset (one VGPR for the whole kernel).
+    // With 64-bit per-lane pointers every piece beyond the 4-KiB immediate range costs an address pair -- the compiler kept two
+    // dozen of them live, which is what pushed a 12-deep ring over the 256 registers of a two-wave SIMD.
+    auto tile_ptr = [&](int64_t tile) { return x8 + (size_t)tile * (KS8 * 64); };
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto ld = [&](u32x4 &dst, const u32x4 *piece) {
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(lane_off), "s"(piece) : "memory");
+    };
 
     u32x4 ring[RING];
     // one tile: KS8 x (wait for the oldest load, four MFMAs, refill the slot RING pieces ahead -- past the tile's end from `xn`)
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             }
             const int sp = s + RING;
             const u32x4 *src = (sp < KS8) ? xp + sp * 64 : xn + (sp - KS8) * 64;
-            nt_load(ring[s % RING], src);
+            ld(ring[s % RING], src);
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
                 bq[b][0] = nb[b][0];
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     };
     auto prime = [&](const u32x4 *xp) {
 #pragma unroll
-        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
+        for (int d = 0; d < RING; ++d) ld(ring[d], xp + d * 64);
     };
 
     // ---- 1. sample tiles g = gw, gw + total, ...: per query the largest LOWER end among the tile's valid rows

@@ -65,6 +65,7 @@ struct crh_index {
     int64_t x8_cap_tiles = 0, i8_dirty_from = 0;
     int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
+    int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -282,7 +283,8 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 // ---- int8 nomination (crh_i8.hpp)
 bool i8_use(const crh_index *h, int nq)
 {
-    return h->i8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan && h->seed_tiles == 4096;
+    return h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
+           h->seed_tiles == 4096;
 }
 
 // the copy covers the index: (re)allocate with the capacity, requantise the tiles touched since the last scan.  Running out of
@@ -414,7 +416,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     // <= batch_q queries at the default sample size: seed scan, threshold and main scan are ONE launch (k_scan_fused: every wave's
     // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
     // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
-    if (!wide && h->fused_scan && h->seed_tiles == 4096 && h->ksteps != 64) {
+    if (!wide && h->fused_scan && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
         const int blocks = scan_blocks(h, ntiles);
         const int waves = blocks * kWaves;
         const int Gf = (int)std::min<int64_t>(std::min(waves, 4096), ntiles);
@@ -1048,6 +1050,23 @@ int crh_debug_select_stamps(unsigned long long *out)
     return CRH_OK;
 }
 #endif
+
+int crh_index_set_nomination(crh_index *h, int mode)
+{
+    if (!h) return fail(CRH_E_INVALID, "index is NULL");
+    if (mode < CRH_NOMINATE_BF16_3 || mode > CRH_NOMINATE_INT8) return fail(CRH_E_INVALID, "unknown nomination mode %d", mode);
+    h->nominate_max = mode;
+    if (mode == CRH_NOMINATE_INT8) h->i8_strikes = 0;   // asking for it again gives the copy another chance
+    return CRH_OK;
+}
+
+int crh_index_get_nomination(crh_index *h, int *mode_out)
+{
+    if (!h || !mode_out) return fail(CRH_E_INVALID, "NULL argument");
+    const bool one_launch = h->fused_scan && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
+    *mode_out = i8_use(h, 1) ? CRH_NOMINATE_INT8 : (one_launch ? CRH_NOMINATE_BF16 : CRH_NOMINATE_BF16_3);
+    return CRH_OK;
+}
 
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap, int force_fallback)
 {

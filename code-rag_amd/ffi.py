@@ -17,8 +17,9 @@ LIB_PATH = Path(os.environ.get("CODERAG_HIP_LIB", PKG_DIR / "lib" / "libcoderag_
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_NODEVICE, E_INTERNAL = 0, -1, -2, -3, -4, -5
 DTYPE_F32, DTYPE_BF16 = 0, 1
+NOMINATE_BF16_3, NOMINATE_BF16, NOMINATE_INT8 = 0, 1, 2
 MAX_FILTERS, MAX_K = 8, 1024
-ABI_VERSION = 2        # CRH_ABI_VERSION of include/coderag_hip.h
+ABI_VERSION = 3        # CRH_ABI_VERSION of include/coderag_hip.h
 
 # every symbol include/coderag_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -27,6 +28,7 @@ EXPORTS = (
     "crh_index_tombstone_filter", "crh_index_compact", "crh_index_export", "crh_index_import",
     "crh_index_count", "crh_index_clear", "crh_index_reserve", "crh_index_read_rows",
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
+    "crh_index_set_nomination", "crh_index_get_nomination",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
@@ -136,6 +138,8 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_search_finish.argtypes = [vp, vp]
     L.crh_search_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
     L.crh_index_set_tuning.argtypes = [vp, i32, i32, i32, i32]
+    L.crh_index_set_nomination.argtypes = [vp, i32]
+    L.crh_index_get_nomination.argtypes = [vp, C.POINTER(i32)]
     L.crh_index_set_profiling.argtypes = [vp, i32]
     L.crh_index_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.crh_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
@@ -438,6 +442,16 @@ class Index:
     def set_tuning(self, seed_tiles: int = 0, wave_cand_cap: int = 0, query_cand_cap: int = 0,
                    force_fallback: int = -1) -> None:
         check(lib().crh_index_set_tuning(self._handle(), seed_tiles, wave_cand_cap, query_cand_cap, force_fallback))
+
+    def set_nomination(self, mode: int) -> None:
+        """The most advanced way the index may nominate a <= 64-query batch: NOMINATE_BF16_3 / NOMINATE_BF16 / NOMINATE_INT8."""
+        check(lib().crh_index_set_nomination(self._handle(), mode))
+
+    def nomination(self) -> int:
+        """The mode the next <= 64-query batch would use (the index may have fallen back by itself)."""
+        out = C.c_int32(0)
+        check(lib().crh_index_get_nomination(self._handle(), C.byref(out)))
+        return int(out.value)
 
     def search(self, queries, k: int, filters=None, row_base: int = 0, out_scores=None, out_rows=None,
                stream: int = 0):

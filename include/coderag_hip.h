@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRH_ABI_VERSION 2
+#define CRH_ABI_VERSION 3
 
 /* status codes */
 #define CRH_OK 0
@@ -180,6 +180,21 @@ int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_lau
  * regrow-and-rerun path runs, 2 = make the one-launch scan's grid-wide wait time out so its recovery path runs, 0 = off. */
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
+
+/* How a batch of up to 64 queries is NOMINATED (every returned id and score is decided by the canonical f32 arithmetic on the
+ * stored rows whatever the mode; results are bit-identical across modes):
+ *   CRH_NOMINATE_BF16_3  seed scan, threshold, main scan over the bf16 tiles as three launches
+ *   CRH_NOMINATE_BF16    the same in one launch (grid-wide waits; needs the whole grid resident)
+ *   CRH_NOMINATE_INT8    one launch over the int8 copy of the rows (half the bytes of the pass; +1 byte per element and 4 per
+ *                        row of device memory, derived from the stored rows, never part of a snapshot) -- the default where
+ *                        it exists (dim 384 / 768 / 1536).
+ * set: the most advanced mode the index may use (it still falls back by itself: no memory for the copy, a grid-wide wait that
+ * timed out, three consecutive batches whose int8 candidate buffers overflowed).  get: the mode the next batch would use. */
+#define CRH_NOMINATE_BF16_3 0
+#define CRH_NOMINATE_BF16 1
+#define CRH_NOMINATE_INT8 2
+int crh_index_set_nomination(crh_index *h, int mode);
+int crh_index_get_nomination(crh_index *h, int *mode_out);
 
 
 /* Merge nlists sorted per-shard lists ([nlists, nq, k] device f32 / int64, padded with

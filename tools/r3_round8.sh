@@ -1,9 +1,9 @@
 #!/bin/bash
-# variants of k_scan_i8 (ring depth, fixed or handed-out tiles), one box, headline bench each
+# variants of k_scan_i8 (ring depth), one box, headline bench each, interleaved
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for v in r8dyn r8st r12st r6dyn r8dyn r8st; do
+for v in $VARIANTS; do
 CODERAG_HIP_LIB=$GRAFT_REPO_ROOT/code-rag_amd/lib/libcoderag_hip_$v.so timeout -k 10 300 python bench.py --legs none --steps 50 --warmup 10 > gpurun_out/r3v_$v.json 2> gpurun_out/r3v_$v.err || { tail -n 5 gpurun_out/r3v_$v.err; exit 1; }
 python - $v <<'PY'
 import json,sys
