@@ -66,6 +66,8 @@ struct crh_index {
     int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
+    int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay (its selection step costs more: 100 k
+                                            // encoder embeddings took 0.38 ms per batch against 0.18 ms); CODERAG_HIP_I8_MIN_ROWS
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
@@ -284,7 +286,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 bool i8_use(const crh_index *h, int nq)
 {
     return h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
-           h->seed_tiles == 4096;
+           h->seed_tiles == 4096 && h->count >= h->i8_min_rows;
 }
 
 // the copy covers the index: (re)allocate with the capacity, requantise the tiles touched since the last scan.  Running out of
@@ -595,6 +597,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         const char *e8 = getenv("CODERAG_HIP_I8");
         h->i8 = h->fused_scan && dim != 1024 && !(e8 && e8[0] == '0');   // (dim 1024: the query image + the threshold phase exceed LDS)
         if (h->i8) h->qcap = 131072;   // ~33 k candidates per query and 10M rows on Gaussian data (crh_i8.hpp)
+        if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
     }
     h->dtype = dtype;
     h->ncols = n_code_cols;

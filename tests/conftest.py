@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library nominates from its int8 copy only from 1M rows up (below that the bf16 scan is faster).  The tests' corpora are
+# far smaller, and the copy is the newest code: let every index of the GPU tier use it, so that each parity test (filters,
+# tombstones, ties, short batches, ...) also pins the int8 path.  The bf16 scans are pinned by the tests that switch the copy
+# off (test_fused_scan_equals_the_three_kernel_form_and_the_oracle) and by test_search_fullsize_gpu.py's default-policy case.
+os.environ.setdefault("CODERAG_HIP_I8_MIN_ROWS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

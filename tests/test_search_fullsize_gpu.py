@@ -5,6 +5,7 @@ need a 10M-row CPU scan:
   * shards     : two 5M-row shards searched separately and merged by crh_merge_topk == the 10M-row search, bit for bit
                  (the 8-GPU configuration in miniature);
   * filter     : a payload filter selecting 1M of the rows == the oracle run on exactly those 1M rows;
+  * modes      : nominated from the int8 copy (the default from 1M rows), from the bf16 tiles in one launch and in three: identical bytes;
   * idempotent : the same search twice gives identical bytes;
   * wide       : a 512-query call (two passes of k_scan_wide) == the same queries searched 64 at a time.
 """
@@ -56,6 +57,16 @@ def test_full_size_properties(gpu):
     assert all(len(set(row)) == K for row in r)
     # planted
     assert np.array_equal(r[:8, 0], sub_rows[planted]) and np.all(np.abs(s[:8, 0] - 1.0) < 4e-3)
+    # the three nomination modes (int8 copy -- the default at this size --, bf16 tiles in one launch, in three) agree bit for bit
+    assert full.nomination() == ffi.NOMINATE_INT8
+    for mode in (ffi.NOMINATE_BF16, ffi.NOMINATE_BF16_3):
+        full.set_nomination(mode)
+        assert full.nomination() == mode
+        sm, rm = full.search(q, K)
+        assert np.array_equal(rm, r) and np.array_equal(sm.view(np.uint32), s.view(np.uint32)), mode
+        assert full.stats()["fallback_used"] == 0
+    full.set_nomination(ffi.NOMINATE_INT8)
+    assert full.nomination() == ffi.NOMINATE_INT8
     # idempotent
     s2, r2 = full.search(q, K)
     assert np.array_equal(r, r2) and np.array_equal(s.view(np.uint32), s2.view(np.uint32))

@@ -661,3 +661,32 @@ def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
     _exact(idx, x, q, 20, True)
     assert idx.stats()["fallback_used"] == 0          # three strikes: this index now scans its bf16 rows
     idx.close()
+
+
+def test_int8_nomination_starts_at_a_row_count_and_can_be_switched(gpu, monkeypatch):
+    """Below CODERAG_HIP_I8_MIN_ROWS (default 1M) a pass is too short for the copy to pay: the index reports the bf16 one-launch
+    scan; past it, the int8 copy; crh_index_set_nomination caps the mode; results never change."""
+    ffi = _ffi()
+    monkeypatch.setenv("CODERAG_HIP_I8_MIN_ROWS", "50000")
+    rng = np.random.default_rng(35)
+    x = rng.standard_normal((60_000, D), dtype=np.float32)
+    q = rng.standard_normal((16, D), dtype=np.float32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=len(x))
+    idx.append(x[:40_000])
+    assert idx.nomination() == ffi.NOMINATE_BF16
+    _exact(idx, x[:40_000], q, 30, True)
+    idx.append(x[40_000:])
+    assert idx.nomination() == ffi.NOMINATE_INT8
+    _exact(idx, x, q, 30, True)
+    for mode in (ffi.NOMINATE_BF16_3, ffi.NOMINATE_BF16, ffi.NOMINATE_INT8):
+        idx.set_nomination(mode)
+        assert idx.nomination() == mode
+        _exact(idx, x, q, 30, True)
+    with pytest.raises(ffi.NativeError):
+        idx.set_nomination(7)
+    idx.close()
+    monkeypatch.delenv("CODERAG_HIP_I8_MIN_ROWS")
+    small = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=1000)
+    small.append(x[:1000])
+    assert small.nomination() == ffi.NOMINATE_BF16          # the library's default: 1M rows
+    small.close()
