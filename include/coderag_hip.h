@@ -181,7 +181,8 @@ int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_lau
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
 
-/* How a batch of up to 64 queries is NOMINATED (every returned id and score is decided by the canonical f32 arithmetic on the
+/* (No counterpart in the reference: it leaves the search strategy to the Qdrant server, embeddings/client.py:96-102,132-157.)
+ * How a batch of up to 64 queries is NOMINATED (every returned id and score is decided by the canonical f32 arithmetic on the
  * stored rows whatever the mode; results are bit-identical across modes):
  *   CRH_NOMINATE_BF16_3  seed scan, threshold, main scan over the bf16 tiles as three launches
  *   CRH_NOMINATE_BF16    the same in one launch (grid-wide waits; needs the whole grid resident)
