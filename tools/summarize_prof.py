@@ -76,10 +76,14 @@ def main(src: str, dst: str, pmc_scan: str | None = None) -> None:
                  if "k_scan" in kn and "wide" not in kn and "hbm_read_bytes_corrected" in k and "hbm_write_bytes" in k]
         if not cands or not out["bench_line"]:
             raise SystemExit("no scan kernel with FETCH_SIZE and WRITE_SIZE rows (or no bench line) under " + src)
-        kn = max(cands)[1]
+        def norm(kn_):
+            m_ = re.search(r"(k_scan\w*<[\d, ]+>)", kn_)
+            return m_.group(1).replace(" ", "") if m_ else kn_
+        want = out["bench_line"]["roofline"].get("kernel")       # the kernel the headline's roofline names, when it was profiled
+        named = [c for c in cands if norm(c[1]) == want]
+        kn = max(named or cands)[1]
         k = out["kernels"][kn]
-        m = re.search(r"(k_scan\w*<[\d, ]+>)", kn)
-        name = m.group(1).replace(" ", "") if m else kn
+        name = norm(kn)
         rows = int(re.search(r"(\d+)x\d+ ", out["bench_line"]["config"]["workload"].split(": ", 1)[1]).group(1))
         json.dump({"source": f"{dst}.json ({src}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py)",
                    "kernel": name, "rows": rows, "fetch_size_kib_mean": k["pmc"]["FETCH_SIZE"]["mean"],
