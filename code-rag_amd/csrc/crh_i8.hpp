@@ -187,7 +187,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const int h = lane >> 5;
 
     CRH_STAMP(0);
-    for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
     if (tid < 64) qcnt_l[tid] = 0u;
     if (tid == 0) next_m = WAVES;
     // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
@@ -201,7 +200,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         // + 128: the f32 evaluation of 128 * dotH + dotL (both exact integers below 2^24) rounds once, by <= 2^30 * 2^-24 = 64
         Bq[b] = (dn * (Qn + gn) + 127.0f * sqrt_dim * gn) * 1.0001f + 128.0f;
     }
-    __syncthreads();
 
     const int total = gridDim.x * WAVES;
     const int gw = blockIdx.x * WAVES + wave;
@@ -288,6 +286,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     {
         int g = gw;
         if (g < G) prime(tile_ptr((int64_t)g * S));
+        // the query image comes in behind the first corpus loads: 96 KB per workgroup that the first tile would otherwise wait for
+        for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
+        __syncthreads();
         while (g < G) {
             const int gn_ = g + total;
             const int64_t tile = (int64_t)g * S;

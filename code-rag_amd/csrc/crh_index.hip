@@ -596,7 +596,8 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         h->fused_scan = !(e && e[0] == '0');
         const char *e8 = getenv("CODERAG_HIP_I8");
         h->i8 = h->fused_scan && dim != 1024 && !(e8 && e8[0] == '0');   // (dim 1024: the query image + the threshold phase exceed LDS)
-        if (h->i8) h->qcap = 131072;   // ~33 k candidates per query and 10M rows on Gaussian data (crh_i8.hpp)
+        // candidates per query and 10M Gaussian rows behind the int8 scan: ~38 k (bf16 store), ~90 k (f32 store: wider intervals)
+        if (h->i8) h->qcap = dtype == CRH_DTYPE_F32 ? 262144 : 131072;
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
     }
     h->dtype = dtype;
