@@ -30,7 +30,23 @@ namespace crh {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// OR of a 32-bit word over the wave, as a scalar: four DPP steps inside each row of 16 lanes, then the four row results.
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
+{
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1 (zeros shifted in)
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 15) | (uint32_t)__builtin_amdgcn_readlane((int)x, 31) |
+           (uint32_t)__builtin_amdgcn_readlane((int)x, 47) | (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+#ifndef CRH_I8_SAMPLE
+#define CRH_I8_SAMPLE 4096
+#endif
+constexpr int kI8SampleTiles = CRH_I8_SAMPLE;   // sample tiles behind the thresholds of k_scan_i8 (the workgroup keeps one query's maxima in LDS)
 constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H in [-127, 127], L in [-64, 63]
 
 // ------------------------------------------------------------------ bf16 tiles -> int8 tiles + per-row scale
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     static_assert(KS8 % RING == 0, "the ring must divide the pieces of a tile (slot s % RING holds piece s of every tile)");
     constexpr int NT = WAVES * 64, NQS = QB * 32, NB = NT < 1024 ? NT : 1024;
     __shared__ u32x4 qs[QB * 2 * KS8 * 64];
-    __shared__ uint32_t col[4096];
+    __shared__ uint32_t col[kI8SampleTiles];
     __shared__ unsigned int hist[(NT / 64) * 256];
     __shared__ unsigned int bcast[2];
     __shared__ unsigned int fast[NB + 256 + 2 * (NT / 64) + 8];
@@ -215,6 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     };
 
     u32x4 ring[RING];
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // one tile: KS8 x (wait for the oldest load, four MFMAs, refill the slot RING pieces ahead -- past the tile's end from `xn`)
     auto scan_tile = [&](const u32x4 *xp, const u32x4 *xn, i32x16 (&acc)[QB][2]) {
         asm volatile("" ::: "memory");   // (keeps the query image out of the loop-invariant registers, as in k_scan)
@@ -237,9 +254,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             nt_wait<RING - 1>(ring[s % RING]);
             const i32x4 xa = __builtin_bit_cast(i32x4, ring[s % RING]);
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                acc[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][0]), acc[b][0], 0, 0, 0);
-                acc[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][1]), acc[b][1], 0, 0, 0);
+            for (int b = 0; b < QB; ++b) {   // (the first piece accumulates onto the constant 0: no 64 register clears per tile)
+                acc[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][0]), s == 0 ? zero16 : acc[b][0], 0, 0, 0);
+#if !defined(CRH_I8_DBG) || CRH_I8_DBG != 1   // (timing ablation 1: no L MFMAs -- wrong results)
+                acc[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, bq[b][1]), s == 0 ? zero16 : acc[b][1], 0, 0, 0);
+#else
+                acc[b][1] = zero16;
+#endif
             }
             const int sp = s + RING;
             const u32x4 *src = (sp < KS8) ? xp + sp * 64 : xn + (sp - KS8) * 64;
@@ -255,27 +276,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     // the intervals of a tile's 16 x QB accumulators of this lane, given the tile's 32 row scales (scalar registers: the tile is
     // wave-uniform).  The two candidates of a select are made opaque first: left alone, the compiler turns the select into ONE
     // load with a lane-dependent index, i.e. spills the scales to scratch and reads them back through the vector-memory counter.
+    auto row_scale = [&](const float (&sr)[32], int r) {
+        const int rowa = (r & 3) + 8 * (r >> 2);
+        float sa = sr[rowa], sb = sr[rowa + 4];
+        asm volatile("" : "+s"(sa), "+v"(sb));     // (one of the two may stay in its scalar register: v_cndmask takes it as it is)
+        return h ? sb : sa;
+    };
+    // two values per instruction (v_pk_fma / v_pk_mul / v_pk_add): the two query blocks of one accumulator row, or two rows of one block
     auto intervals = [&](const i32x16 (&acc)[QB][2], const float (&sr)[32], float (&hi)[QB][16]) {
+        const f32x2 k128 = {128.0f, 128.0f}, c2 = {c_abs, c_abs};
+        if (QB == 2) {
+            const f32x2 sq2 = {sq[0], sq[QB - 1]}, B2 = {Bq[0], Bq[QB - 1]};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowa = (r & 3) + 8 * (r >> 2);
-            float sa = sr[rowa], sb = sr[rowa + 4];
-            asm volatile("" : "+v"(sa), "+v"(sb));
-            const float s_r = h ? sb : sa;
+            for (int r = 0; r < 16; ++r) {
+                const float s_r = row_scale(sr, r);
+                const f32x2 fh = {(float)acc[0][0][r], (float)acc[QB - 1][0][r]}, fl = {(float)acc[0][1][r], (float)acc[QB - 1][1][r]};
+                const f32x2 f = __builtin_elementwise_fma(fh, k128, fl);
+                const f32x2 w = sq2 * f32x2{s_r, s_r};
+                const f32x2 u = __builtin_elementwise_fma(w, f + B2, c2);
+                hi[0][r] = u.x;
+                hi[QB - 1][r] = u.y;
+            }
+        } else {
+            const f32x2 sq2 = {sq[0], sq[0]}, B2 = {Bq[0], Bq[0]};
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                const float f = fmaf((float)acc[b][0][r], 128.0f, (float)acc[b][1][r]);
-                hi[b][r] = fmaf(s_r * sq[b], f + Bq[b], c_abs);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 s2 = {row_scale(sr, r), row_scale(sr, r + 1)};
+                const f32x2 fh = {(float)acc[0][0][r], (float)acc[0][0][r + 1]}, fl = {(float)acc[0][1][r], (float)acc[0][1][r + 1]};
+                const f32x2 f = __builtin_elementwise_fma(fh, k128, fl);
+                const f32x2 u = __builtin_elementwise_fma(sq2 * s2, f + B2, c2);
+                hi[0][r] = u.x;
+                hi[0][r + 1] = u.y;
             }
         }
     };
     // the lower end of an interval from its upper end: hi - 2 (s_r s_q B_q + c), one more allowance for the f32 evaluation
     auto lower_end = [&](float hi_v, const float (&sr)[32], int b, int r) {
-        const int rowa = (r & 3) + 8 * (r >> 2);
-        float sa = sr[rowa], sb = sr[rowa + 4];
-        asm volatile("" : "+v"(sa), "+v"(sb));
-        const float s_r = h ? sb : sa;
-        return hi_v - 2.0f * fmaf(s_r * sq[b], Bq[b], c_abs) - 2e-6f;
+        return hi_v - 2.0f * fmaf(row_scale(sr, r) * sq[b], Bq[b], c_abs) - 2e-6f;
     };
     auto prime = [&](const u32x4 *xp) {
 #pragma unroll
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             float sr[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
-            i32x16 acc[QB][2] = {};
+            i32x16 acc[QB][2];
             scan_tile(xp, xn, acc);
             float hi[QB][16];
             intervals(acc, sr, hi);
@@ -366,28 +403,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         float sr[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
-        i32x16 acc[QB][2] = {};
+        i32x16 acc[QB][2];
         scan_tile(xp, xn, acc);
         float hi[QB][16];
         intervals(acc, sr, hi);
-        bool any = false;
+        // Which of the lane's 16 x QB values pass: ONE word per lane (bit 16 b + r), the validity of the lane's rows folded in, and
+        // its OR over the wave as a scalar.  The emit code below is then entered only for the (block, accumulator) positions where
+        // some lane passes, on SCALAR tests -- a tile holds ~8 candidates, and 32 ballots each followed by a branch on a vector
+        // compare cost 160 us of a 1.34 ms pass (ablation, round 3).
+        uint32_t pmask = 0u;
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            float mh = hi[b][0];
+        for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mh = fmaxf(mh, hi[b][r]);
-            any = any || (mh >= tq[b]);
+            for (int r = 0; r < 16; ++r) pmask |= (hi[b][r] >= tq[b]) ? (1u << (b * 16 + r)) : 0u;
+        {
+            const uint32_t t = vmask >> (4 * h);          // the lane's rows are (r & 3) + 8 (r >> 2) + 4 h: nibbles 0, 2, 4, 6 of t
+            const uint32_t v16 = (t & 0xfu) | ((t >> 4) & 0xf0u) | ((t >> 8) & 0xf00u) | ((t >> 12) & 0xf000u);
+            pmask &= v16 | (v16 << 16);
         }
-        if (__ballot(any) != 0ull && vmask != 0u) {
+#if defined(CRH_I8_DBG) && CRH_I8_DBG == 2   // (timing ablation 2: no emit loop -- no candidates)
+        asm volatile("" ::"v"(pmask));
+        const uint32_t any_u = 0u;
+#else
+        const uint32_t any_u = wave_or_u32(pmask);
+#endif
+        if (any_u != 0u) {
             const uint32_t rowbase = (uint32_t)(tile * 32);
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool pass = ((vmask >> row) & 1u) && (hi[b][r] >= tq[b]);
-                    const unsigned long long pm = __ballot(pass);
-                    if (pm != 0ull) {
+                    if ((any_u >> (b * 16 + r)) & 1u) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool pass = (pmask >> (b * 16 + r)) & 1u;
+                        const unsigned long long pm = __ballot(pass);
                         const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
                         const unsigned int pos = wcnt + pre;
                         if (pass && pos < (unsigned int)wave_cap) {
