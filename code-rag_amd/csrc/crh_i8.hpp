@@ -16,7 +16,7 @@
 //   * k_select<.., I8>: L = k-th largest lo of the candidates (again a lower bound of the true k-th score), survivors = hi >= L,
 //     canonical re-score and exact top-k as before.
 // Results are bit-identical to the bf16 scan's and the oracle's.  On N(0, I)/sqrt(D) rows at D = 768: s_r ~ 9.6e-4, |d| ~ 8.0
-// (max 8.6), interval half-width ~ 8.3e-3 = 0.23 sigma of the score distribution; ~33 k candidates and ~700 survivors per query
+// (max 8.6), interval half-width ~ 8.3e-3 = 0.23 sigma of the score distribution; ~21 k candidates and ~800 survivors per query
 // and 10M rows, against a pass that reads 7.68 + 0.04 GB instead of 15.36 GB.  Rows with outlier elements get a large s_r and
 // are simply nominated more often; when the candidate buffers overflow the host re-runs the batch on the bf16 scan
 // (finish_pending) and, after repeated overflows, leaves the int8 copy unused for that index.
@@ -43,10 +43,7 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
            (uint32_t)__builtin_amdgcn_readlane((int)x, 47) | (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-#ifndef CRH_I8_SAMPLE
-#define CRH_I8_SAMPLE 4096
-#endif
-constexpr int kI8SampleTiles = CRH_I8_SAMPLE;   // sample tiles behind the thresholds of k_scan_i8 (the workgroup keeps one query's maxima in LDS)
+constexpr int kI8SampleTiles = 8192;   // most sample tiles behind the thresholds of k_scan_i8 (a workgroup keeps one query's maxima in LDS)
 constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H in [-127, 127], L in [-64, 63]
 
 // ------------------------------------------------------------------ bf16 tiles -> int8 tiles + per-row scale
@@ -173,8 +170,8 @@ __global__ __launch_bounds__(64) void k_prep_queries_i8(const float *__restrict_
 
 // ------------------------------------------------------------------ the scan over the int8 copy, one launch
 // Phases as k_scan_fused (sample tiles -> grid-wide wait -> thresholds -> grid-wide wait -> all tiles), with two differences:
-// the sample is G = min(4096, tiles) strided tiles walked by whoever's turn it is (the accumulators are not kept across the
-// waits: four accumulator sets per wave leave no room, and re-reading 100 MB of samples costs 1.3 % of the pass), and the
+// the sample is G = min(8192, tiles) strided tiles walked by whoever's turn it is (the accumulators are not kept across the
+// waits: four accumulator sets per wave leave no room, and re-reading 200 MB of samples costs 2.6 % of the pass), and the
 // per-row interval arithmetic of the header comment replaces the single score.
 // LDS: query image QB * 2 * KS8 KiB (96 KB at D = 768) + the threshold phase's 16 + 8 + 5 KB.  WAVES = 8: 64 accumulator
 // registers + a 16-deep ring of loads per wave need more than the 128 registers a 16-wave workgroup leaves each wave.

@@ -66,6 +66,8 @@ struct crh_index {
     int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
+    int i8_sample = kI8SampleTiles;         // sample tiles behind the int8 scan's thresholds: 8192 halves the candidates of 4096 for 100 MB more
+                                            // sample reads (-22 us per batch on one index, tools/sample_ab.py); CODERAG_HIP_I8_SAMPLE
     int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay (its selection step costs more: 100 k
                                             // encoder embeddings took 0.38 ms per batch against 0.18 ms); CODERAG_HIP_I8_MIN_ROWS
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
@@ -286,7 +288,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 bool i8_use(const crh_index *h, int nq)
 {
     return h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
-           h->seed_tiles == 4096 && h->count >= h->i8_min_rows;
+           (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
 // the copy covers the index: (re)allocate with the capacity, requantise the tiles touched since the last scan.  Running out of
@@ -401,7 +403,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         hipLaunchKernelGGL(k_prep_queries_i8, dim3(h->batch_q), dim3(64), 0, st, w.qn, h->dim, w.qfrag8, w.qpar);
         CRH_HIP(hipGetLastError());
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
-        const int G8 = (int)std::min<int64_t>(kI8SampleTiles, ntiles);
+        const int G8 = (int)std::min<int64_t>(h->seed_tiles == 4096 ? h->i8_sample : h->seed_tiles, ntiles);
         const int S8 = (int)std::max<int64_t>(1, ntiles / G8);
         const float c_abs = 0.5f * margin + 1e-5f;
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
@@ -605,6 +607,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         // candidates per query and 10M Gaussian rows behind the int8 scan: ~38 k (bf16 store), ~90 k (f32 store: wider intervals)
         if (h->i8) h->qcap = dtype == CRH_DTYPE_F32 ? 262144 : 131072;
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
+        if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
     }
     h->dtype = dtype;
     h->ncols = n_code_cols;
