@@ -285,9 +285,10 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 }
 
 // ---- int8 nomination (crh_i8.hpp)
-bool i8_use(const crh_index *h, int nq)
+constexpr int kI8MaxK = 256;   // beyond this k the threshold sits so low that the int8 intervals nominate several 100 k rows per query
+bool i8_use(const crh_index *h, int nq, int k)
 {
-    return h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
+    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
            (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
@@ -396,10 +397,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     CRH_HIP(hipGetLastError());
 
     // <= batch_q queries, nominated from the int8 copy (crh_i8.hpp): half the bytes of the pass, same results
-    if (i8_use(h, nq)) {
+    if (i8_use(h, nq, k)) {
         CRH_TRY(i8_sync(h, st));
     }
-    if (i8_use(h, nq)) {   // (i8_sync may have given the copy up for lack of memory)
+    if (i8_use(h, nq, k)) {   // (i8_sync may have given the copy up for lack of memory)
         hipLaunchKernelGGL(k_prep_queries_i8, dim3(h->batch_q), dim3(64), 0, st, w.qn, h->dim, w.qfrag8, w.qpar);
         CRH_HIP(hipGetLastError());
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
@@ -1080,7 +1081,7 @@ int crh_index_get_nomination(crh_index *h, int *mode_out)
 {
     if (!h || !mode_out) return fail(CRH_E_INVALID, "NULL argument");
     const bool one_launch = h->fused_scan && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
-    *mode_out = i8_use(h, 1) ? CRH_NOMINATE_INT8 : (one_launch ? CRH_NOMINATE_BF16 : CRH_NOMINATE_BF16_3);
+    *mode_out = i8_use(h, 1, 100) ? CRH_NOMINATE_INT8 : (one_launch ? CRH_NOMINATE_BF16 : CRH_NOMINATE_BF16_3);
     return CRH_OK;
 }
 
@@ -1162,7 +1163,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         // (the filter mask lives in the workspace: stream order puts its rebuild behind the previous batch's scan)
         CRH_TRY(build_mask(h, w, filters, n_filters, &mask, st));
         CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
-        p.used_i8 = h->count > 0 && i8_use(h, b);   // (as enqueue_batch just decided)
+        p.used_i8 = h->count > 0 && i8_use(h, b, k);   // (as enqueue_batch just decided)
         h->pending.push_back(p);
     }
     if (!out_on_device || !queries_on_device) {

@@ -188,7 +188,7 @@ int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int qu
  *   CRH_NOMINATE_BF16    the same in one launch (grid-wide waits; needs the whole grid resident)
  *   CRH_NOMINATE_INT8    one launch over the int8 copy of the rows (half the bytes of the pass; +1 byte per element and 4 per
  *                        row of device memory, derived from the stored rows, never part of a snapshot) -- the default where
- *                        it exists (dim 384 / 768 / 1536).
+ *                        it exists (dim 384 / 768 / 1536), from 1M rows up, for k <= 256.
  * set: the most advanced mode the index may use (it still falls back by itself: no memory for the copy, a grid-wide wait that
  * timed out, three consecutive batches whose int8 candidate buffers overflowed).  get: the mode the next batch would use. */
 #define CRH_NOMINATE_BF16_3 0
