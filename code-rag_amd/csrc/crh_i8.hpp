@@ -194,6 +194,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     __shared__ unsigned int qcnt_l[64];   // candidates of this workgroup per query, counted as they are emitted
     __shared__ unsigned int wpre[WAVES + 1];
     __shared__ int next_m;                // tiles handed out so far to this workgroup's waves (main loop)
+    __shared__ int next_g;                // ... and sample tiles (the same hand-out: the older wave of a SIMD would otherwise wait at
+                                          // the grid-wide wait for the younger one to get through its fixed share)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +203,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 
     CRH_STAMP(0);
     if (tid < 64) qcnt_l[tid] = 0u;
-    if (tid == 0) next_m = WAVES;
+    if (tid == 0) {
+        next_m = WAVES;
+        next_g = WAVES;
+    }
     // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
     const float dn = bits_f32(*dn_bits);
     float sq[QB], Bq[QB];
@@ -324,7 +329,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
         __syncthreads();
         while (g < G) {
-            const int gn_ = g + total;
+            int mg = 0;
+            if (lane == 0) mg = atomicAdd(&next_g, 1);
+            mg = __builtin_amdgcn_readfirstlane(mg);
+            const int gn_ = (mg / WAVES) * total + (int)blockIdx.x * WAVES + (mg % WAVES);
             const int64_t tile = (int64_t)g * S;
             const u32x4 *xp = tile_ptr(tile);
             const u32x4 *xn = gn_ < G ? tile_ptr((int64_t)gn_ * S) : (gw < ntiles ? tile_ptr(gw) : xp);
