@@ -49,47 +49,69 @@ constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H 
 // ------------------------------------------------------------------ bf16 tiles -> int8 tiles + per-row scale
 // One wave per tile.  dn_bits: f32 bits of the running maximum of |d|_2 (+ allowance for the f32 evaluation) over all rows
 // ever quantised; positive floats order like their bits, so atomicMax keeps it.
-__global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt, u32x4 *__restrict__ x8, float *__restrict__ srow,
-                                                   unsigned int *__restrict__ dn_bits, int64_t t0, int ksteps)
+// F32: the rows come from the f32 master of an f32 store (row-major [rows][dim]) instead of the bf16 tiles, so the copy carries no
+// bf16 rounding and the intervals of an f32 store are as narrow as a bf16 store's.
+template <bool F32>
+__global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt, const float *__restrict__ xf32, u32x4 *__restrict__ x8,
+                                                   float *__restrict__ srow, unsigned int *__restrict__ dn_bits, int64_t t0, int ksteps,
+                                                   int64_t count)
 {
     const int64_t tile = t0 + blockIdx.x;
     const int lane = threadIdx.x, row = lane & 31, hh = lane >> 5;
+    const bool live = tile * 32 + row < count;          // (rows past the count: whatever the buffers hold there becomes zeros)
     const u32x4 *tp = xt + (size_t)tile * ksteps * 64;
-    float m = 0.f;
-    for (int s = 0; s < ksteps; ++s) {
-        const u32x4 v = tp[s * 64 + lane];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int ks8 = ksteps >> 1, dim = ksteps * 16;
+    const float4 *fr = reinterpret_cast<const float4 *>(xf32 + ((size_t)tile * 32 + row) * dim);   // (F32 only)
+    // the lane's 16 elements of piece p: elements [32p + 16hh, + 16) of its row
+    auto fetch16 = [&](int p, float (&v)[16]) {
+        if (!live) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            m = fmaxf(m, fabsf(bf16_bits_f32(w[e] & 0xffffu)));
-            m = fmaxf(m, fabsf(bf16_bits_f32(w[e] >> 16)));
+            for (int j = 0; j < 16; ++j) v[j] = 0.f;
+        } else if (F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 f = fr[(32 * p + 16 * hh) / 4 + j];
+                v[4 * j] = f.x;
+                v[4 * j + 1] = f.y;
+                v[4 * j + 2] = f.z;
+                v[4 * j + 3] = f.w;
+            }
+        } else {
+            const int s = 2 * p + hh;                    // bf16 piece holding those elements for the tile's 32 rows
+            const u32x4 a = tp[s * 64 + row], b = tp[s * 64 + 32 + row];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[2 * e] = bf16_bits_f32(w[e] & 0xffffu);
+                v[2 * e + 1] = bf16_bits_f32(w[e] >> 16);
+            }
         }
+    };
+    float m = 0.f;
+    for (int p = 0; p < ks8; ++p) {
+        float v[16];
+        fetch16(p, v);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(v[j]));
     }
     m = fmaxf(m, __shfl_xor(m, 32));
-    if (!(m < INFINITY)) m = 0.f;                       // (a row holding inf / nan: quantised to zeros, scale 0 -- see below)
+    if (!(m < INFINITY)) m = 0.f;                       // (a row holding inf / nan: quantised to zeros, scale 0)
     const float s_r = m / 127.0f;
     const float inv = m > 0.f ? 127.0f / m : 0.f;
     float dsq = 0.f;
-    const int ks8 = ksteps >> 1;
     for (int p = 0; p < ks8; ++p) {
-        const int s = 2 * p + hh;                        // bf16 piece holding elements [32p + 16hh, + 16) of the tile's rows
-        const u32x4 a = tp[s * 64 + row], b = tp[s * 64 + 32 + row];
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float v[16];
+        fetch16(p, v);
         uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float x = bf16_bits_f32(t ? (w[e] >> 16) : (w[e] & 0xffffu));
-                float y = x * inv;
-                y = (y == y) ? y : 0.f;
-                float X = rintf(y);
-                X = fminf(fmaxf(X, -127.f), 127.f);
-                const float d = y - X;
-                dsq = fmaf(d, d, dsq);
-                const int j = 2 * e + t;                 // byte j of the lane's 16
-                o[j >> 2] |= ((uint32_t)(int)X & 0xffu) << (8 * (j & 3));
-            }
+        for (int j = 0; j < 16; ++j) {
+            float y = v[j] * inv;
+            y = (y == y) ? y : 0.f;
+            float X = rintf(y);
+            X = fminf(fmaxf(X, -127.f), 127.f);
+            const float d = y - X;
+            dsq = fmaf(d, d, dsq);
+            o[j >> 2] |= ((uint32_t)(int)X & 0xffu) << (8 * (j & 3));   // byte j of the lane's 16
         }
         u32x4 pk;
         pk.x = o[0];

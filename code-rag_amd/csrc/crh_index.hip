@@ -324,8 +324,12 @@ int i8_sync(crh_index *h, hipStream_t st)
     CRH_TRY(i8_alloc(h));
     if (!h->i8) return CRH_OK;
     if (h->i8_dirty_from < ntiles) {
-        hipLaunchKernelGGL(k_requant_i8, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->x8, h->srow, h->i8stat,
-                           h->i8_dirty_from, h->ksteps);
+        if (h->dtype == CRH_DTYPE_F32)
+            hipLaunchKernelGGL(k_requant_i8<true>, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->xf32, h->x8, h->srow,
+                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count);
+        else
+            hipLaunchKernelGGL(k_requant_i8<false>, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->xf32, h->x8, h->srow,
+                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count);
         CRH_HIP(hipGetLastError());
         h->i8_dirty_from = ntiles;
     }
@@ -406,7 +410,9 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
         const int G8 = (int)std::min<int64_t>(h->seed_tiles == 4096 ? h->i8_sample : h->seed_tiles, ntiles);
         const int S8 = (int)std::max<int64_t>(1, ntiles / G8);
-        const float c_abs = 0.5f * margin + 1e-5f;
+        // what separates a row's canonical score from the exact dot of the QUANTISED-FROM rows and the canonical query: the two f32
+        // summation orders only -- the copy of an f32 store is quantised from its f32 master, not from the bf16 tiles
+        const float c_abs = 1.5e-4f * (h->dim > 768 ? (float)h->dim / 768.f : 1.f) + 1e-5f;
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
         CRH_TRY(launch_scan_i8(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
@@ -605,8 +611,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         h->fused_scan = !(e && e[0] == '0');
         const char *e8 = getenv("CODERAG_HIP_I8");
         h->i8 = h->fused_scan && dim != 1024 && !(e8 && e8[0] == '0');   // (dim 1024: the query image + the threshold phase exceed LDS)
-        // candidates per query and 10M Gaussian rows behind the int8 scan: ~38 k (bf16 store), ~90 k (f32 store: wider intervals)
-        if (h->i8) h->qcap = dtype == CRH_DTYPE_F32 ? 262144 : 131072;
+        if (h->i8) h->qcap = 131072;   // ~21 k candidates per query and 10M Gaussian rows behind the int8 scan (37 k with 4096 sample tiles)
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
         if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
     }
