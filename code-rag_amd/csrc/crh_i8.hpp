@@ -9,7 +9,7 @@
 //     | x.q - s_r s_q dot |  =  s_r s_q | d.Q + X.g + d.g |  <=  s_r s_q * B_q,
 //     B_q = dn * (|Q|_2 + gn) + 127 sqrt(D) * gn,        dn >= |d|_2 of EVERY row (kept by k_requant_i8), gn >= |g|_2
 // by Cauchy-Schwarz -- no assumption on the data.  Each row therefore has an interval [lo, hi] = s_r s_q (dot -+ B_q) -+ c that
-// contains its canonical score (c: the f32 summation-order / store-rounding allowance the bf16 scan's margin already used).
+// contains its canonical score (c: the allowance for the canonical score's own f32 summation order, as in the bf16 scan's margin).
 //   * threshold: tau_q = k-th largest over the sample tiles of max_rows(lo): k distinct rows score at least that, so the true
 //     k-th score does too;
 //   * nomination: every row with hi >= tau_q; the candidate carries (hi, lo);
@@ -23,7 +23,8 @@
 //
 // Layout of the copy: tile = 32 rows; piece p of a tile = 1 KiB = elements [32p, 32p + 32) of its 32 rows as ONE MFMA operand
 // (lane l: row l & 31, elements 32p + 16 (l >> 5) .. + 15, one byte each).  Pieces of a tile are consecutive: D / 32 KiB per tile.
-// The copy is derived from the bf16 tiles (k_requant_i8), never stored in snapshots, and brought up to date lazily before a scan.
+// The copy is derived from the stored rows (k_requant_i8: the bf16 tiles, or the f32 master of an f32 store), never stored in
+// snapshots, and brought up to date lazily before a scan.
 #pragma once
 
 namespace crh {
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
 constexpr int kI8SampleTiles = 8192;   // most sample tiles behind the thresholds of k_scan_i8 (a workgroup keeps one query's maxima in LDS)
 constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H in [-127, 127], L in [-64, 63]
 
-// ------------------------------------------------------------------ bf16 tiles -> int8 tiles + per-row scale
+// ------------------------------------------------------------------ stored rows -> int8 tiles + per-row scale
 // One wave per tile.  dn_bits: f32 bits of the running maximum of |d|_2 (+ allowance for the f32 evaluation) over all rows
 // ever quantised; positive floats order like their bits, so atomicMax keeps it.
 // F32: the rows come from the f32 master of an f32 store (row-major [rows][dim]) instead of the bf16 tiles, so the copy carries no
