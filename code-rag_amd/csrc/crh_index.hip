@@ -1115,8 +1115,16 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
 
     // force_fallback (testing): 1 = start from absurdly small candidate buffers so the regrow-and-rerun path runs;
     // 2 = the one-launch scan's first grid-wide wait expects an arrival too many, so its time-out path runs
-    const int wc = h->force_fallback == 1 ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
-    const int qc = h->force_fallback == 1 ? 8 : std::max(h->qcap, h->ws.ws_qcap);
+    int wc = h->force_fallback == 1 ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
+    int qc = h->force_fallback == 1 ? 8 : std::max(h->qcap, h->ws.ws_qcap);
+    if (h->force_fallback != 1 && i8_use(h, 1, k)) {
+        // the int8 intervals nominate a fixed FRACTION of the rows (the thresholds come from a fixed number of sample tiles):
+        // ~21 k per query and ~660 per wave of the int8 scan at 10M rows.  The defaults hold that twice over up to 10M rows; beyond,
+        // the buffers grow with the index (the int8 scan cannot regrow them after the fact: an overflow sends the batch to bf16)
+        const int64_t scale = next_pow2(ceil_div(h->count, 10000000));
+        wc = (int)std::max<int64_t>(wc, std::min<int64_t>(2048 * scale, 1 << 18));
+        qc = (int)std::max<int64_t>(qc, std::min<int64_t>(131072 * scale, 1 << 24));
+    }
     CRH_TRY(ensure_workspace(h, h->ws, wc, qc));
 
     const float *q_dev = queries;
