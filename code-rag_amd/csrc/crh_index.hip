@@ -1160,6 +1160,8 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     for (int q0 = 0, b = 0; q0 < nq; q0 += b) {
         const int left = nq - q0;
         b = (h->wide_ok && left > h->batch_q) ? std::min(kWideQ, left) : std::min(h->batch_q, left);
+        // up to two passes over the int8 copy (2 x ~1.55 ms at 10M rows) beat one wide pass over the bf16 tiles (~4.2 ms)
+        if (left > h->batch_q && left <= 2 * h->batch_q && h->count > 0 && i8_use(h, h->batch_q, k)) b = h->batch_q;
         if (h->next_slot >= kStatusSlots) CRH_TRY(finish_pending(h, st));
         crh_index::Workspace &w = h->ws;
         Pending p{};

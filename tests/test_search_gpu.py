@@ -248,7 +248,8 @@ def test_other_embedding_dimensions(gpu, dim, bf16):
     s, r = idx.search(q, 20)
     es, er = orc.cosine_search(x, q, 20, bf16=bf16)
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
-    assert idx.stats()["batches"] == {384: 1, 1024: 2, 1536: 3}[dim]      # 70 queries: one wide pass | 64 + 6 | 32 + 32 + 6
+    # 70 queries: 64 + 6 over the int8 copy (cheaper than one wide pass over the bf16 tiles) | 64 + 6 | 32 + 32 + 6
+    assert idx.stats()["batches"] == {384: 2, 1024: 2, 1536: 3}[dim]
     idx.close()
     with pytest.raises(ffi.NativeError):
         ffi.Index(100, ffi.DTYPE_F32, 64)
@@ -444,6 +445,7 @@ def test_wide_scan_against_the_oracle(gpu, bf16, dim, n, nq, k):
     q[nq // 2] = x[n // 3] * 2.0
     codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
     idx = ffi.Index(dim, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n, n_code_cols=1)
+    idx.set_nomination(ffi.NOMINATE_BF16)     # (with the int8 copy in play 65..128 queries run as two 64-query passes over it: below)
     idx.append(x, codes)
     dead = rng.choice(n, n // 7, replace=False)
     idx.tombstone(dead)
@@ -690,3 +692,18 @@ def test_int8_nomination_starts_at_a_row_count_and_can_be_switched(gpu, monkeypa
     small.append(x[:1000])
     assert small.nomination() == ffi.NOMINATE_BF16          # the library's default: 1M rows
     small.close()
+
+
+def test_65_to_128_queries_take_two_passes_over_the_int8_copy_instead_of_one_wide_pass(gpu):
+    """Two passes over the int8 copy are cheaper than one wide pass over the bf16 tiles; beyond 128 queries the wide scan is."""
+    ffi = _ffi()
+    rng = np.random.default_rng(36)
+    x = rng.standard_normal((30_000, D), dtype=np.float32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=len(x))
+    idx.append(x)
+    assert idx.nomination() == ffi.NOMINATE_INT8
+    for nq, batches in ((65, 2), (128, 2), (129, 1), (64, 1)):
+        q = rng.standard_normal((nq, D), dtype=np.float32)
+        _exact(idx, x, q, 40, True)
+        assert idx.stats()["batches"] == batches, (nq, idx.stats())
+    idx.close()
