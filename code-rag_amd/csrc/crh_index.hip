@@ -57,6 +57,8 @@ struct crh_index {
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     bool fused_scan = true;   // <= batch_q queries: seed scan + threshold + main scan in one launch (CODERAG_HIP_FUSED_SCAN=0: three)
+    int fused_cooldown = 0;   // batches still to run in the three-launch form after a grid-wide wait timed out (then the one-launch
+                              // forms get another chance: the cause -- another stream's kernels holding CUs -- is usually transient)
     // int8 nomination copy (crh_i8.hpp): derived from xt, brought up to date before a scan (i8_sync); tiles >= i8_dirty_from are stale
     bool i8 = false;          // <= batch_q queries are nominated from the copy (dim 384 / 768 / 1536; CODERAG_HIP_I8=0: never)
     u32x4 *x8 = nullptr;
@@ -288,7 +290,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 constexpr int kI8MaxK = 256;   // beyond this k the threshold sits so low that the int8 intervals nominate several 100 k rows per query
 bool i8_use(const crh_index *h, int nq, int k)
 {
-    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan &&
+    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan && h->fused_cooldown == 0 &&
            (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
@@ -433,7 +435,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     // <= batch_q queries at the default sample size: seed scan, threshold and main scan are ONE launch (k_scan_fused: every wave's
     // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
     // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
-    if (!wide && h->fused_scan && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
+    if (!wide && h->fused_scan && h->fused_cooldown == 0 && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
         const int blocks = scan_blocks(h, ntiles);
         const int waves = blocks * kWaves;
         const int Gf = (int)std::min<int64_t>(std::min(waves, 4096), ntiles);
@@ -454,6 +456,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         h->stats.batches += 1;
         return CRH_OK;
     }
+    if (h->fused_cooldown > 0) h->fused_cooldown -= 1;
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     if (wide)
@@ -516,9 +519,9 @@ int finish_pending(crh_index *h, hipStream_t st)
             if (++attempts > 6) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
             if (s.bar_timeout) {
                 // A grid-wide wait of the one-launch scan gave up: some workgroup was not resident for ~0.5 s (other streams'
-                // kernels holding CUs).  The batch's results are void; this index goes back to the three-launch form, which needs
-                // no co-residency, and the batch is run again.
-                h->fused_scan = false;
+                // kernels holding CUs).  The batch's results are void; this index goes to the three-launch form, which needs no
+                // co-residency, for this batch (run again) and the next 1024.
+                h->fused_cooldown = 1024;
                 h->stats.fallback_used |= 2;
             } else if (via_i8) {
                 // the int8 intervals of this data / this k are too wide for the candidate buffers: the batch goes to the bf16 scan
@@ -1085,7 +1088,7 @@ int crh_index_set_nomination(crh_index *h, int mode)
 int crh_index_get_nomination(crh_index *h, int *mode_out)
 {
     if (!h || !mode_out) return fail(CRH_E_INVALID, "NULL argument");
-    const bool one_launch = h->fused_scan && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
+    const bool one_launch = h->fused_scan && h->fused_cooldown == 0 && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
     *mode_out = i8_use(h, 1, 100) ? CRH_NOMINATE_INT8 : (one_launch ? CRH_NOMINATE_BF16 : CRH_NOMINATE_BF16_3);
     return CRH_OK;
 }
