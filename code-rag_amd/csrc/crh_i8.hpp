@@ -19,7 +19,7 @@
 // (max 8.6), interval half-width ~ 8.3e-3 = 0.23 sigma of the score distribution; ~21 k candidates and ~800 survivors per query
 // and 10M rows, against a pass that reads 7.68 + 0.04 GB instead of 15.36 GB.  Rows with outlier elements get a large s_r and
 // are simply nominated more often; when the candidate buffers overflow the host re-runs the batch on the bf16 scan
-// (finish_pending) and, after repeated overflows, leaves the int8 copy unused for that index.
+// (finish_pending) and, after three overflows in a row, rests the int8 copy of that index for 4096 batches.
 //
 // Layout of the copy: tile = 32 rows; piece p of a tile = 1 KiB = elements [32p, 32p + 32) of its 32 rows as ONE MFMA operand
 // (lane l: row l & 31, elements 32p + 16 (l >> 5) .. + 15, one byte each).  Pieces of a tile are consecutive: D / 32 KiB per tile.

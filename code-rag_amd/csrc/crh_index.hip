@@ -65,7 +65,8 @@ struct crh_index {
     float *srow = nullptr;
     unsigned int *i8stat = nullptr;
     int64_t x8_cap_tiles = 0, i8_dirty_from = 0;
-    int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused)
+    int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused ...
+    int i8_cooldown = 0;      // ... for this many batches; then it gets ONE more try, and the next overflow rests it again)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
     int i8_sample = kI8SampleTiles;         // sample tiles behind the int8 scan's thresholds: 8192 halves the candidates of 4096 for 100 MB more
@@ -290,7 +291,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 constexpr int kI8MaxK = 256;   // beyond this k the threshold sits so low that the int8 intervals nominate several 100 k rows per query
 bool i8_use(const crh_index *h, int nq, int k)
 {
-    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_strikes < 3 && nq <= h->batch_q && h->fused_scan && h->fused_cooldown == 0 &&
+    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_cooldown == 0 && nq <= h->batch_q && h->fused_scan && h->fused_cooldown == 0 &&
            (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
@@ -436,6 +437,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
     // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
     if (!wide && h->fused_scan && h->fused_cooldown == 0 && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
+        if (h->i8_cooldown > 0 && !h->i8_suppress) h->i8_cooldown -= 1;
         const int blocks = scan_blocks(h, ntiles);
         const int waves = blocks * kWaves;
         const int Gf = (int)std::min<int64_t>(std::min(waves, 4096), ntiles);
@@ -457,6 +459,7 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         return CRH_OK;
     }
     if (h->fused_cooldown > 0) h->fused_cooldown -= 1;
+    if (!wide && h->i8_cooldown > 0 && !h->i8_suppress) h->i8_cooldown -= 1;
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
     if (wide)
@@ -527,6 +530,10 @@ int finish_pending(crh_index *h, hipStream_t st)
                 // the int8 intervals of this data / this k are too wide for the candidate buffers: the batch goes to the bf16 scan
                 // (whose buffers regrow if they must); three such batches in a row and the copy is left unused
                 h->i8_strikes += 1;
+                if (h->i8_strikes >= 3) {
+                    h->i8_strikes = 2;
+                    h->i8_cooldown = 4096;
+                }
                 h->i8_suppress = true;
                 h->stats.fallback_used |= 4;
                 via_i8 = false;
@@ -1081,7 +1088,7 @@ int crh_index_set_nomination(crh_index *h, int mode)
     if (!h) return fail(CRH_E_INVALID, "index is NULL");
     if (mode < CRH_NOMINATE_BF16_3 || mode > CRH_NOMINATE_INT8) return fail(CRH_E_INVALID, "unknown nomination mode %d", mode);
     h->nominate_max = mode;
-    if (mode == CRH_NOMINATE_INT8) h->i8_strikes = 0;   // asking for it again gives the copy another chance
+    if (mode == CRH_NOMINATE_INT8) h->i8_strikes = h->i8_cooldown = 0;   // asking for it again gives the copy another chance at once
     return CRH_OK;
 }
 

@@ -190,7 +190,8 @@ int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int qu
  *                        row of device memory, derived from the stored rows, never part of a snapshot) -- the default where
  *                        it exists (dim 384 / 768 / 1536), from 1M rows up, for k <= 256.
  * set: the most advanced mode the index may use (it still falls back by itself: no memory for the copy, a grid-wide wait that
- * timed out, three consecutive batches whose int8 candidate buffers overflowed).  get: the mode the next batch would use. */
+ * timed out -- 1024 batches in the three-launch form --, three consecutive batches whose int8 candidate buffers overflowed --
+ * 4096 batches on the bf16 scan, then one more try).  get: the mode the next batch would use. */
 #define CRH_NOMINATE_BF16_3 0
 #define CRH_NOMINATE_BF16 1
 #define CRH_NOMINATE_INT8 2

@@ -646,7 +646,7 @@ def test_int8_nomination_with_masses_of_identical_rows(gpu, bf16):
 
 def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
     """Intervals too wide for the buffers (here: buffers made tiny) -> the batch is run again on the bf16 scan (bit 2 of
-    fallback_used), which regrows ITS buffers (bit 0); after three such batches the copy is left unused."""
+    fallback_used), which regrows ITS buffers (bit 0); after three such batches the copy is rested (4096 batches, then one more try)."""
     ffi = _ffi()
     rng = np.random.default_rng(34)
     x = rng.standard_normal((40_000, D), dtype=np.float32)
@@ -661,7 +661,8 @@ def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
         assert idx.stats()["fallback_used"] & 4
     idx.set_tuning(force_fallback=0)
     _exact(idx, x, q, 20, True)
-    assert idx.stats()["fallback_used"] == 0          # three strikes: this index now scans its bf16 rows
+    assert idx.stats()["fallback_used"] == 0          # three strikes: this index scans its bf16 rows for a while
+    assert idx.nomination() == ffi.NOMINATE_BF16
     idx.close()
 
 
