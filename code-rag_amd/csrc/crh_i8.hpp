@@ -33,17 +33,6 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// OR of a 32-bit word over the wave, as a scalar: four DPP steps inside each row of 16 lanes, then the four row results.
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
-{
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1 (zeros shifted in)
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
-    return (uint32_t)__builtin_amdgcn_readlane((int)x, 15) | (uint32_t)__builtin_amdgcn_readlane((int)x, 31) |
-           (uint32_t)__builtin_amdgcn_readlane((int)x, 47) | (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
-
 constexpr int kI8SampleTiles = 8192;   // most sample tiles behind the thresholds of k_scan_i8 (a workgroup keeps one query's maxima in LDS)
 constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H in [-127, 127], L in [-64, 63]
 
@@ -216,6 +205,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     __shared__ float tau_s[NQS];
     __shared__ unsigned int qcnt_l[64];   // candidates of this workgroup per query, counted as they are emitted
     __shared__ unsigned int wpre[WAVES + 1];
+    __shared__ unsigned int wcnt_l[WAVES];   // candidates of each wave so far (unclamped): lanes reserve their list positions here
+    __shared__ float hwf[64];                // s_q * B_q of each query: a row's interval is 2 (s_r * hwf[q] + c) wide
     __shared__ int next_m;                // tiles handed out so far to this workgroup's waves (main loop)
     __shared__ int next_g;                // ... and sample tiles (the same hand-out: the older wave of a SIMD would otherwise wait at
                                           // the grid-wide wait for the younger one to get through its fixed share)
@@ -226,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 
     CRH_STAMP(0);
     if (tid < 64) qcnt_l[tid] = 0u;
+    if (tid < WAVES) wcnt_l[tid] = 0u;
     if (tid == 0) {
         next_m = WAVES;
         next_g = WAVES;
@@ -240,12 +232,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         sq[b] = s_q;
         // + 128: the f32 evaluation of 128 * dotH + dotL (both exact integers below 2^24) rounds once, by <= 2^30 * 2^-24 = 64
         Bq[b] = (dn * (Qn + gn) + 127.0f * sqrt_dim * gn) * 1.0001f + 128.0f;
+        if (wave == 0 && lane < 32) hwf[qi] = s_q * Bq[b];
     }
 
     const int total = gridDim.x * WAVES;
     const int gw = blockIdx.x * WAVES + wave;
     u32x4 *mylist = wave_lists + (size_t)gw * wave_cap;
-    unsigned int wcnt = 0;
     // A tile's address is wave-uniform: loads take it as a SCALAR base plus the lane's byte offset (one VGPR for the whole kernel).
     // With 64-bit per-lane pointers every piece beyond the 4-KiB immediate range costs an address pair -- the compiler kept two
     // dozen of them live, which is what pushed a 12-deep ring over the 256 registers of a two-wave SIMD.
@@ -435,10 +427,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         scan_tile(xp, xn, acc);
         float hi[QB][16];
         intervals(acc, sr, hi);
-        // Which of the lane's 16 x QB values pass: ONE word per lane (bit 16 b + r), the validity of the lane's rows folded in, and
-        // its OR over the wave as a scalar.  The emit code below is then entered only for the (block, accumulator) positions where
-        // some lane passes, on SCALAR tests -- a tile holds ~8 candidates, and 32 ballots each followed by a branch on a vector
-        // compare cost 160 us of a 1.34 ms pass (ablation, round 3).
+        // Which of the lane's 16 x QB values pass: one word per lane (bit 16 b + r), the validity of the lane's rows folded in.
         uint32_t pmask = 0u;
 #pragma unroll
         for (int b = 0; b < QB; ++b)
@@ -449,37 +438,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             const uint32_t v16 = (t & 0xfu) | ((t >> 4) & 0xf0u) | ((t >> 8) & 0xf00u) | ((t >> 12) & 0xf000u);
             pmask &= v16 | (v16 << 16);
         }
-#if defined(CRH_I8_DBG) && CRH_I8_DBG == 2   // (timing ablation 2: no emit loop -- no candidates)
+#if defined(CRH_I8_DBG) && CRH_I8_DBG == 2   // (timing ablation 2: no emit code -- no candidates)
         asm volatile("" ::"v"(pmask));
-        const uint32_t any_u = 0u;
-#else
-        const uint32_t any_u = wave_or_u32(pmask);
+        pmask = 0u;
 #endif
-        if (any_u != 0u) {
-            const uint32_t rowbase = (uint32_t)(tile * 32);
+        if (pmask != 0u) {
+            // Every lane emits its OWN candidates (the set bits of its word): it reserves list positions with one LDS atomic and
+            // walks its bits -- one or two as a rule, a tile holds ~4 candidates over 64 lanes.  The form before this one entered a
+            // ballot / prefix / store block per (block, accumulator) position with a candidate, ~230 cycles each, 70 us of the pass.
+            // The candidate's lower end is worked out in the hand-over (it needs the row's scale: one gather there, nothing here).
+            const uint32_t rowbase = (uint32_t)(tile * 32) + 4u * (uint32_t)h;
+            unsigned int pos = atomicAdd(&wcnt_l[wave], (unsigned int)__popc(pmask));
+            uint32_t m = pmask;
+            do {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1u;
+                // hi[bit >> 4][bit & 15] without indexing registers by a lane-dependent number: compare-and-select over the 16 x QB values
+                float hv = hi[0][0];
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
+                for (int b = 0; b < QB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if ((any_u >> (b * 16 + r)) & 1u) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool pass = (pmask >> (b * 16 + r)) & 1u;
-                        const unsigned long long pm = __ballot(pass);
-                        const unsigned int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-                        const unsigned int pos = wcnt + pre;
-                        if (pass && pos < (unsigned int)wave_cap) {
-                            u32x4 e;
-                            e.x = f32_bits(hi[b][r]);
-                            e.y = rowbase + row;
-                            e.z = (uint32_t)(b * 32 + (lane & 31));
-                            e.w = f32_bits(lower_end(hi[b][r], sr, b, r));
-                            mylist[pos] = e;
-                            atomicAdd(&qcnt_l[b * 32 + (lane & 31)], 1u);
-                        }
-                        wcnt += (unsigned int)__popcll(pm);
-                    }
+                    for (int rr = 0; rr < 16; ++rr) hv = (bit == b * 16 + rr) ? hi[b][rr] : hv;
+                const int r = bit & 15;
+                if (pos < (unsigned int)wave_cap) {
+                    u32x4 e;
+                    e.x = f32_bits(hv);
+                    e.y = rowbase + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    e.z = (uint32_t)((bit >> 4) * 32 + (lane & 31));
+                    e.w = 0u;
+                    mylist[pos] = e;
+                    atomicAdd(&qcnt_l[e.z], 1u);
                 }
-            }
+                ++pos;
+            } while (m != 0u);
         }
         xp = xn;
         i = inext;
@@ -493,6 +484,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     // ---- hand the workgroup's candidates over to the per-query lists: the per-query counts are known (counted at emit), so
     // one range per (workgroup, query) is reserved with 64 global atomics and ONE sweep copies the entries, eight loads deep
     if (lane == 0) {
+        const unsigned int wcnt = wcnt_l[wave];
         wpre[wave + 1] = wcnt < (unsigned int)wave_cap ? wcnt : (unsigned int)wave_cap;
         atomicMax(&status->max_wave_cnt, wcnt);
         if (wcnt > (unsigned int)wave_cap) atomicAdd(&status->wave_overflow, 1u);
@@ -500,6 +492,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     __syncthreads();
     unsigned int *base = reinterpret_cast<unsigned int *>(qs);   // [64] start of this workgroup's range in each query's list
     unsigned int *off = base + 64;                                // [64] entries placed so far
+    // (hwf sits in its own LDS words: the query image that base / off overlay is dead, the factors are not)
     if (tid < 64) {
         const unsigned int n = qcnt_l[tid];
         base[tid] = n ? atomicAdd(&qcount[tid], n) : 0u;
@@ -519,6 +512,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const u32x4 *wl = wave_lists + (size_t)blockIdx.x * WAVES * wave_cap;
     for (unsigned int e0 = tid; e0 < nall; e0 += NT * 8) {
         u32x4 cnd[8];
+        float s_r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned int e = e0 + j * NT;
@@ -532,6 +526,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned int e = e0 + j * NT;
+            s_r[j] = e < nall ? srow[cnd[j].y] : 0.f;      // the scale of the candidate's row (row number = position in srow)
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int e = e0 + j * NT;
             if (e < nall) {
                 const unsigned int q = cnd[j].z & 63u;
                 const unsigned int idx = base[q] + atomicAdd(&off[q], 1u);
@@ -540,7 +539,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
                     o.x = cnd[j].x;
                     o.y = cnd[j].y;
                     qlist[(size_t)q * qcap + idx] = o;
-                    qlo[(size_t)q * qcap + idx] = bits_f32(cnd[j].w);
+                    // lower end = upper end - 2 (s_r s_q B_q + c), one more allowance for the f32 evaluation
+                    qlo[(size_t)q * qcap + idx] = bits_f32(cnd[j].x) - 2.0f * fmaf(s_r[j], hwf[q], c_abs) - 2e-6f;
                 }
             }
         }
