@@ -1066,6 +1066,26 @@ int crh_debug_read_ceiling(crh_index *h, void *stream)
     CRH_TRY(build_mask(h, w, nullptr, 0, &mask, static_cast<hipStream_t>(stream)));
     return launch_scan<2>(h, w, scan_blocks(h, ntiles), static_cast<hipStream_t>(stream), mask, (int)ntiles, 1, w.ws_wave_cap, w.ws_qcap, h->status);
 }
+
+// Moves the int8 copy to a fresh allocation (the new one is taken BEFORE the old one is released, so it lands elsewhere): the
+// speed of a pass depends on where the copy sits (tools/alloc_modes.py), this lets one index try several places.
+int crh_debug_i8_move(crh_index *h)
+{
+    if (!h || !h->i8 || !h->x8) return fail(CRH_E_INVALID, "no int8 copy to move");
+    DeviceGuard g(h->device);
+    CRH_HIP(hipDeviceSynchronize());
+    const int ks8 = h->dim / 32;
+    u32x4 *nx = nullptr;
+    float *ns = nullptr;
+    CRH_HIP(hipMalloc(reinterpret_cast<void **>(&nx), (size_t)h->x8_cap_tiles * ks8 * 1024));
+    CRH_HIP(hipMalloc(reinterpret_cast<void **>(&ns), (size_t)h->x8_cap_tiles * 32 * sizeof(float)));
+    dev_free(h->x8);
+    dev_free(h->srow);
+    h->x8 = nx;
+    h->srow = ns;
+    h->i8_dirty_from = 0;
+    return CRH_OK;
+}
 #endif  // CRH_ENABLE_DEBUG
 
 #ifdef CRH_FUSED_STAMPS   // a measurement build only (tools/fused_stamps.py): per-workgroup phase clocks of the last k_scan_fused

@@ -35,7 +35,7 @@ EXPORTS = (
     "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed", "crh_encoder_finish",
 )
 # exported by lib/libcoderag_hip_debug.so only (same sources built with -DCRH_ENABLE_DEBUG; tools/ and kernel tests)
-DEBUG_EXPORTS = ("crh_debug_gemm_variant", "crh_debug_read_ceiling")
+DEBUG_EXPORTS = ("crh_debug_gemm_variant", "crh_debug_read_ceiling", "crh_debug_i8_move")
 DEBUG_LIB_PATH = Path(os.environ.get("CODERAG_HIP_DEBUG_LIB", PKG_DIR / "lib" / "libcoderag_hip_debug.so"))
 
 RR_NAME_BYTES, RR_MAX_ENTITIES, RR_ENTITY_BYTES = 64, 8, 48
@@ -161,6 +161,7 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
         debug = True
         L.crh_debug_gemm_variant.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.crh_debug_read_ceiling.argtypes = [vp, vp]
+        L.crh_debug_i8_move.argtypes = [vp]
     for name in EXPORTS + (DEBUG_EXPORTS if debug else ()):
         if name != "crh_last_error":
             getattr(L, name).restype = i32

@@ -329,6 +329,10 @@ int crh_encoder_finish(void *stream);
  * the scan's achieved GB/s is to be read against (tools/read_ceiling.py). */
 int crh_debug_read_ceiling(crh_index *h, void *stream);
 
+/* Measurement support: moves the int8 nomination copy of an index to a fresh device allocation (taken before the old one is
+ * released) and marks it for requantisation -- lets one index try several places in HBM (tools/i8_places.py). */
+int crh_debug_i8_move(crh_index *h);
+
 /* Timing ablations of the GEMM main loop (variant 0 = the real kernel; others skip a pipeline stage and return
  * garbage).  Development aid used by tools/gemm_ablate.py; not part of the product path. */
 int crh_debug_gemm_variant(const void *x, const void *w, const float *bias, void *y, int T, int N, int K,
