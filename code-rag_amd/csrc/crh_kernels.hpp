@@ -7,7 +7,8 @@
 // HBM layout of the corpus ("tiled bf16"): rows are grouped in tiles of 32; one tile holds
 // KSTEPS = dim/16 pieces of 1 KiB; piece s is exactly the A operand of one
 // v_mfma_f32_32x32x16_bf16 for k = 16s..16s+15: lane l = 32h + r holds the 8 bf16
-// X[32*tile + r][16s + 8h + 0..7].  A wave therefore streams a tile with 1-KiB fully
+// X[32*tile + r][16s + 8h + 0..7], and finds them at slot 2r + h of the piece (the two halves of a row
+// side by side: see piece_slot).  A wave therefore streams a tile with 1-KiB fully
 // coalesced dwordx4 loads, straight into MFMA operand registers -- no LDS round trip,
 // no transposition, every HBM byte fetched exactly once.  The (<= 64) queries sit in LDS
 // in the matching B-operand layout for the whole kernel.
@@ -77,9 +78,14 @@ __device__ __forceinline__ float unord_f32(uint32_t o)
 __device__ __forceinline__ int lane_id() { return __lane_id(); }
 
 // address (in u32x4 units) of piece (tile, s) lane (h, r)
+// Where the 16 bytes of MFMA lane (h, r) sit inside a 1-KiB piece: the two halves of a ROW are neighbours (32 contiguous bytes per
+// row and piece).  A wave's load of a piece is one contiguous KiB either way; the canonical re-score of a single row, which
+// fetches 64-byte sectors, gets 32 useful bytes per sector instead of 16 (its traffic is what bounds k_select behind the int8 scan).
+__device__ __forceinline__ int piece_slot(int h, int r) { return r * 2 + h; }
+__device__ __forceinline__ int lane_slot(int lane) { return (lane & 31) * 2 + (lane >> 5); }
 __device__ __forceinline__ size_t tiled_index(int64_t tile, int ksteps, int s, int h, int r)
 {
-    return ((size_t)tile * ksteps + s) * 64 + (h * 32 + r);
+    return ((size_t)tile * ksteps + s) * 64 + piece_slot(h, r);
 }
 
 // ------------------------------------------------------------------ append / preprocess
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void k_compact_tiles(const u32x4 *__restrict__
     for (int s = wave; s < ksteps; s += 4) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (old >= 0) v = xt[tiled_index(old >> 5, ksteps, s, h, (int)(old & 31))];
-        bounce[((size_t)blockIdx.x * ksteps + s) * 64 + lane] = v;
+        bounce[((size_t)blockIdx.x * ksteps + s) * 64 + piece_slot(h, r)] = v;
     }
 }
 
@@ -437,7 +443,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     unsigned int wcnt = 0;
 
     int i = gw;
-    const u32x4 *xp = xt + (size_t)(i < nitems ? (int64_t)i * tile_stride : 0) * (KSTEPS * 64) + lane;
+    const int lslot = lane_slot(lane);   // (the lane's 16 bytes inside a piece)
+    const u32x4 *xp = xt + (size_t)(i < nitems ? (int64_t)i * tile_stride : 0) * (KSTEPS * 64) + lslot;
     u32x4 ring[RING];
     if (i < nitems) {
 #pragma unroll
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     while (i < nitems) {
         const int inext = i + total;
         const int64_t tile = (int64_t)i * tile_stride;
-        const u32x4 *xn = (inext < nitems) ? xt + (size_t)((int64_t)inext * tile_stride) * (KSTEPS * 64) + lane : xp;
+        const u32x4 *xn = (inext < nitems) ? xt + (size_t)((int64_t)inext * tile_stride) * (KSTEPS * 64) + lslot : xp;
         const uint32_t vmask = rowmask[tile];  // wave-uniform -> scalar load
         // the query image is loop-invariant: without this the compiler hoists all 96 LDS pieces (384 VGPRs)
         // out of the tile loop and spills; the clobber makes it re-read qs per tile, as intended
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(512) void k_scan_wide(
 
     auto issue = [&](int j) {
         const int64_t tile = (int64_t)((int)blockIdx.x + j * (int)gridDim.x) * tile_stride;
-        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane;
+        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane_slot(lane);   // (the LDS image stays lane-linear)
         u32x4 *dst = ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64;
 #pragma unroll
         for (int p = 0; p < PPW; ++p)
@@ -1083,7 +1090,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     // the tiles that are not samples, r = 0 .. nrem-1 in ascending tile order: below G * S every S-th tile is a sample
     const int nrem = ntiles - G, GS1 = G * (S - 1), Sm1 = S > 1 ? S - 1 : 1;
     auto tile_of = [&](int r) -> int64_t { return r < GS1 ? (int64_t)r + r / Sm1 + 1 : (int64_t)r + G; };
-    auto tile_ptr = [&](int64_t tile) { return xt + (size_t)tile * (KSTEPS * 64) + lane; };
+    const int lslot = lane_slot(lane);
+    auto tile_ptr = [&](int64_t tile) { return xt + (size_t)tile * (KSTEPS * 64) + lslot; };
 
     // One tile: KSTEPS x (wait for the oldest of the RING loads in flight, two MFMAs, refill the slot RING steps ahead -- past the
     // tile's end from the NEXT tile `xn`, so the stream never stops at a tile boundary).  k_scan's inner loop.
@@ -1299,14 +1307,14 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ gmax, int
 __device__ __forceinline__ float canonical_dot_tiled(const u32x4 *__restrict__ xt, int ksteps, uint32_t row,
                                                      const float *qv)
 {
-    // A row is spread over 2*ksteps 16-byte pieces 512 B / 1 KiB apart: 96 separate HBM sectors.  They are fetched 16 at a
-    // time (independent loads, one latency per batch) and then consumed strictly in index order.
-    const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31);
+    // A row is ksteps runs of 32 bytes, 1 KiB apart: 48 separate HBM sectors (96 of 16 useful bytes before the halves of a row
+    // became neighbours).  They are fetched 16 chunks at a time (independent loads, one latency per batch), consumed in index order.
+    const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31) * 2;
     float acc = 0.0f;
     for (int s0 = 0; s0 < ksteps; s0 += 8) {
         u32x4 pk[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pk[j] = xt[base + (size_t)(s0 + (j >> 1)) * 64 + (j & 1) * 32];
+        for (int j = 0; j < 16; ++j) pk[j] = xt[base + (size_t)(s0 + (j >> 1)) * 64 + (j & 1)];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float *qq = qv + (s0 + (j >> 1)) * 16 + (j & 1) * 8;

@@ -322,7 +322,7 @@ class Index:
         return o2n
 
     # ------------------------------------------------------------------ snapshot
-    SNAPSHOT_FORMAT = 2
+    SNAPSHOT_FORMAT = 3                     # 3: inside a 1-KiB piece the 16-byte chunks are ordered [row][half]; 2 (rounds 2-3): [half][row]
     SNAPSHOT_CHUNK_TILES = 1 << 15          # 32768 tiles = 1M rows per transfer (1.5 GiB of tiles at dim 768)
 
     def save(self, directory: str) -> dict:
@@ -381,11 +381,13 @@ class Index:
         import json
         with open(os.path.join(directory, "index.json")) as f:
             meta = json.load(f)
-        want = {"format": self.SNAPSHOT_FORMAT, "dim": self.dim, "dtype": "bf16" if self.dtype == DTYPE_BF16 else "f32",
-                "n_code_cols": self.n_code_cols}
+        want = {"dim": self.dim, "dtype": "bf16" if self.dtype == DTYPE_BF16 else "f32", "n_code_cols": self.n_code_cols}
         for key, val in want.items():
             if meta.get(key) != val:
                 raise NativeError(E_INVALID, f"snapshot {directory} has {key}={meta.get(key)!r}, this index {val!r}")
+        if meta.get("format") not in (2, self.SNAPSHOT_FORMAT):
+            raise NativeError(E_INVALID, f"snapshot {directory} has format={meta.get('format')!r}, this library reads 2 and {self.SNAPSHOT_FORMAT}")
+        old_piece_order = meta.get("format") == 2        # [half][row] chunks inside a piece: reordered chunk by chunk below
         if self.count()[0] != 0:
             raise NativeError(E_INVALID, "load() needs an empty index")
         rows, ntiles, tile_bytes = int(meta["rows"]), int(meta["tiles"]), int(meta["tile_bytes"])
@@ -411,7 +413,10 @@ class Index:
             nt = min(self.SNAPSHOT_CHUNK_TILES, ntiles - t0)
             cbuf = np.ascontiguousarray(codes[:, t0 * 32:(t0 + nt) * 32]) if codes is not None else None
             abuf = np.ascontiguousarray(al[t0:t0 + nt])
-            check(lib().crh_index_import(self._handle(), t0, nt, min(rows, (t0 + nt) * 32), tiles[t0:t0 + nt].ctypes.data,
+            tbuf = tiles[t0:t0 + nt]
+            if old_piece_order:
+                tbuf = np.ascontiguousarray(tbuf.reshape(nt, self.dim // 16, 2, 32, 16).transpose(0, 1, 3, 2, 4))
+            check(lib().crh_index_import(self._handle(), t0, nt, min(rows, (t0 + nt) * 32), tbuf.ctypes.data,
                                          master[t0 * 32:(t0 + nt) * 32].ctypes.data if master is not None else None,
                                          abuf.ctypes.data, cbuf.ctypes.data if cbuf is not None else None))
         got_rows, got_alive = self.count()

@@ -123,7 +123,8 @@ int crh_index_compact(crh_index *h, int64_t *old_to_new_host, int64_t *rows_afte
 /* Snapshot support -- what Qdrant's on-disk volume does for the reference (docker-compose.yml:42-43): the stored image moves
  * VERBATIM between HBM and host buffers (typically an mmap of a file) in chunks of 32-row tiles, so a restored index answers
  * with identical bits.  Per chunk of n_tiles tiles starting at first_tile:
- *   tiles   n_tiles * (dim/16) KiB  the tiled bf16 image the scan streams
+ *   tiles   n_tiles * (dim/16) KiB  the tiled bf16 image the scan streams (ABI 3: inside a 1-KiB piece the 16-byte chunk of
+ *                                   row r, half h sits at slot 2r + h; ABI 2 had h * 32 + r -- ffi.Index.load reorders such files)
  *   master  n_tiles * 32 * dim f32  the normalised f32 rows (dtype F32 only; NULL otherwise)
  *   alive   n_tiles u32             one validity word per tile (tombstones included)
  *   codes   [n_code_cols][n_tiles*32] int32, column after column (NULL when the index has no code columns)

@@ -197,3 +197,35 @@ def test_snapshot_of_10M_rows_under_a_minute(gpu):
         assert t_save + t_load < 60.0, (t_save, t_load)
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_snapshot_of_the_previous_piece_order_still_loads(gpu, tmp_path):
+    """Format 2 (rounds 2-3) kept the 16-byte chunks of a 1-KiB piece as [half][row]; format 3 keeps the two halves of a row side
+    by side.  A format-2 directory -- made here by reordering a fresh snapshot back -- loads into the same index."""
+    import json
+    ffi = _env()
+    rng = np.random.default_rng(41)
+    rows, dim = 4100, 768
+    x = rng.standard_normal((rows, dim)).astype(np.float32)
+    q = rng.standard_normal((7, dim)).astype(np.float32)
+    a = ffi.Index(dim, ffi.DTYPE_BF16, capacity_rows=rows)
+    a.append(x)
+    want = a.search(q, 30)
+    meta = a.save(str(tmp_path))
+    assert meta["format"] == 3
+    ntiles = (rows + 31) // 32
+    t = np.fromfile(tmp_path / "tiles.bin", dtype=np.uint8).reshape(ntiles, dim // 16, 32, 2, 16)       # [tile][piece][row][half][16 B]
+    np.ascontiguousarray(t.transpose(0, 1, 3, 2, 4)).tofile(tmp_path / "tiles.bin")                   # -> [tile][piece][half][row][16 B]
+    meta["format"] = 2
+    with open(tmp_path / "index.json", "w") as f:
+        json.dump(meta, f)
+    b = ffi.Index(dim, ffi.DTYPE_BF16, capacity_rows=rows)
+    b.load(str(tmp_path))
+    got = b.search(q, 30)
+    assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+    assert np.array_equal(a.read_rows(0, rows), b.read_rows(0, rows))
+    meta["format"] = 1
+    with open(tmp_path / "index.json", "w") as f:
+        json.dump(meta, f)
+    with pytest.raises(ffi.NativeError):
+        ffi.Index(dim, ffi.DTYPE_BF16, capacity_rows=rows).load(str(tmp_path))
