@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
             }
         } else {
             const int s = 2 * p + hh;                    // bf16 piece holding those elements for the tile's 32 rows
-            const u32x4 a = tp[s * 64 + piece_slot(0, row)], b = tp[s * 64 + piece_slot(1, row)];
+            const u32x4 a = tp[piece_off(s) + piece_slot(0, row)], b = tp[piece_off(s) + piece_slot(1, row)];
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {

@@ -81,11 +81,15 @@ __device__ __forceinline__ int lane_id() { return __lane_id(); }
 // Where the 16 bytes of MFMA lane (h, r) sit inside a 1-KiB piece: the two halves of a ROW are neighbours (32 contiguous bytes per
 // row and piece).  A wave's load of a piece is one contiguous KiB either way; the canonical re-score of a single row, which
 // fetches 64-byte sectors, gets 32 useful bytes per sector instead of 16 (its traffic is what bounds k_select behind the int8 scan).
+// (Going further -- pieces 2j and 2j+1 interleaved per row, 64 contiguous bytes per row and piece pair, a full sector for the
+// re-score -- was built and measured: a wave's load of one piece then covers half of each of 32 sectors, and the bf16 scan went
+// from 2.33 to 2.69 ms, the wide scan from 8.4 to 9.1 ms, for 7 us less around the int8 pass.  Not kept.)
+__device__ __forceinline__ constexpr int piece_off(int s) { return s * 64; }   // u32x4 units of piece s inside its tile
 __device__ __forceinline__ int piece_slot(int h, int r) { return r * 2 + h; }
 __device__ __forceinline__ int lane_slot(int lane) { return (lane & 31) * 2 + (lane >> 5); }
 __device__ __forceinline__ size_t tiled_index(int64_t tile, int ksteps, int s, int h, int r)
 {
-    return ((size_t)tile * ksteps + s) * 64 + piece_slot(h, r);
+    return (size_t)tile * ksteps * 64 + piece_off(s) + piece_slot(h, r);
 }
 
 // ------------------------------------------------------------------ append / preprocess
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void k_compact_tiles(const u32x4 *__restrict__
     for (int s = wave; s < ksteps; s += 4) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (old >= 0) v = xt[tiled_index(old >> 5, ksteps, s, h, (int)(old & 31))];
-        bounce[((size_t)blockIdx.x * ksteps + s) * 64 + piece_slot(h, r)] = v;
+        bounce[(size_t)blockIdx.x * ksteps * 64 + piece_off(s) + piece_slot(h, r)] = v;
     }
 }
 
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
     u32x4 ring[RING];
     if (i < nitems) {
 #pragma unroll
-        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + piece_off(d));
     }
     while (i < nitems) {
         const int inext = i + total;
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan(
                 if (QB == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
             }
             const int sp = s + RING;
-            const u32x4 *src = (sp < KSTEPS) ? xp + sp * 64 : xn + (sp - KSTEPS) * 64;
+            const u32x4 *src = (sp < KSTEPS) ? xp + piece_off(sp) : xn + piece_off(sp - KSTEPS);
             nt_load(ring[s % RING], src);
             b0 = nb0;
             b1 = nb1;
@@ -639,11 +643,11 @@ __global__ __launch_bounds__(512) void k_scan_wide(
 
     auto issue = [&](int j) {
         const int64_t tile = (int64_t)((int)blockIdx.x + j * (int)gridDim.x) * tile_stride;
-        const u32x4 *src = xt + ((size_t)tile * KSTEPS + wave * PPW) * 64 + lane_slot(lane);   // (the LDS image stays lane-linear)
+        const u32x4 *src = xt + (size_t)tile * KSTEPS * 64 + lane_slot(lane);   // (the LDS image stays lane-linear)
         u32x4 *dst = ring + ((size_t)(j % SLOTS) * KSTEPS + wave * PPW) * 64;
 #pragma unroll
         for (int p = 0; p < PPW; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece_off(wave * PPW + p)),
                                              (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 2 /* nt */);
     };
     for (int j = 0; j < SLOTS - 1 && j < nmine; ++j) issue(j);
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b0), c0, 0, 0, 0);
             if (QB == 2) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, __builtin_bit_cast(bf16x8, b1), c1, 0, 0, 0);
             const int sp = s + RING;
-            const u32x4 *src = (sp < KSTEPS) ? xp + sp * 64 : xn + (sp - KSTEPS) * 64;
+            const u32x4 *src = (sp < KSTEPS) ? xp + piece_off(sp) : xn + piece_off(sp - KSTEPS);
             nt_load(ring[s % RING], src);
             b0 = nb0;
             b1 = nb1;
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     if (has_sample) {
         const u32x4 *xs = tile_ptr(stile);
 #pragma unroll
-        for (int d = 0; d < RING; ++d) nt_load(ring[d], xs + d * 64);
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xs + piece_off(d));
         scan_tile(xs, xp, a0, a1);
         const uint32_t vmask = rowmask[stile];
         float m0 = -INFINITY, m1 = -INFINITY;
@@ -1146,7 +1150,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
         }
     } else if (i < nrem) {
 #pragma unroll
-        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + d * 64);
+        for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + piece_off(d));
     }
     CRH_STAMP(2);
     grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
@@ -1312,8 +1316,8 @@ __device__ __forceinline__ float canonical_dot_tiled(const u32x4 *__restrict__ x
     // chain of 16 additions) and the chunk 8 further on is requested into its place, so the chain runs UNDER the fetches instead
     // of after them (a batch of 16 fetched, then consumed, then the next batch: 103 -> 90 us of the re-score came from the layout,
     // the rest of this loop's time was the two taking turns).  ksteps % 8 == 0.
-    const size_t base = (size_t)(row >> 5) * ksteps * 64 + (row & 31) * 2;
-    auto chunk = [&](int c) { return xt[base + (size_t)(c >> 1) * 64 + (c & 1)]; };   // chunk c = elements [8c, 8c + 8) of the row
+    const size_t base = (size_t)(row >> 5) * ksteps * 64;
+    auto chunk = [&](int c) { return xt[base + piece_off(c >> 1) + piece_slot(c & 1, (int)(row & 31))]; };   // chunk c = elements [8c, 8c + 8) of the row
     const int nchunks = 2 * ksteps;
     float acc = 0.0f;
     u32x4 pk[8];
