@@ -208,6 +208,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     __shared__ unsigned int wcnt_l[WAVES];   // candidates of each wave so far (unclamped): lanes reserve their list positions here
     __shared__ float hwf[64];                // s_q * B_q of each query: a row's interval is 2 (s_r * hwf[q] + c) wide
     __shared__ int next_m;                // tiles handed out so far to this workgroup's waves (main loop)
+    __shared__ unsigned long long cslot[8];   // (slot number << 32) | chunk number of the workgroup's j-th chunk of tiles, in entry j % 8
     __shared__ int next_g;                // ... and sample tiles (the same hand-out: the older wave of a SIMD would otherwise wait at
                                           // the grid-wide wait for the younger one to get through its fixed share)
     const int tid = threadIdx.x;
@@ -221,6 +222,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     if (tid == 0) {
         next_m = WAVES;
         next_g = WAVES;
+        for (int j = 2; j < 8; ++j) cslot[j] = ~0ull;
+        cslot[0] = (unsigned long long)blockIdx.x;
+        cslot[1] = (1ull << 32) | (gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
     const float dn = bits_f32(*dn_bits);
@@ -407,13 +411,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     int i = gw;
     const u32x4 *xp = tile_ptr(i < ntiles ? i : 0);
     while (i < ntiles) {
-        // which wave takes the workgroup's next tile is decided as they go: the SIMD issues its older wave first, and with a fixed
-        // list per wave the younger four finished 80-130 us after the older four (stamps, round 3) on half the loads in flight
-#ifndef CRH_I8_STATIC
-        int mn = 0;
-        if (lane == 0) mn = atomicAdd(&next_m, 1);
-        mn = __builtin_amdgcn_readfirstlane(mn);
-        const int inext = (mn / WAVES) * total + (int)blockIdx.x * WAVES + (mn % WAVES);
+        // Which tile a wave scans next is decided as the pass goes, at both levels.  The pass is cut into chunks of WAVES consecutive
+        // tiles; a workgroup starts on chunk blockIdx.x and draws further chunks from ONE counter in device memory
+        // (status->next_chunk), its waves draw the tiles of a chunk from a counter in LDS.  Inside a workgroup: the SIMD issues its
+        // older wave first, and with a fixed list per wave the younger four finished 80-130 us after the older four on half the
+        // loads in flight.  Across workgroups: the even XCDs stream faster than the odd ones (their workgroups were done ~100 us
+        // before the last); this pass is not purely HBM-bound, so -- unlike the bf16 scan, where the same hand-out only cost its
+        // bookkeeping -- what the early finishers leave does not speed the others up, and sharing the tail does: kernel 1.282 / 1.302 /
+        // 1.285 / 1.283 -> 1.236 / 1.236 / 1.241 / 1.239 ms, interleaved runs on one box (profiles/r03_chunk_feed_ab.txt).  The wave that draws a chunk's first
+        // tile fetches the NEXT chunk's number (one device atomic per WAVES tiles, a tile time ahead of its first use) and publishes
+        // it in LDS with its slot number; a wave reads the entry right after its draw.  Chunks past the end make tiles past the
+        // end: a wave stops at the first one (the counter only grows, so every later draw is past the end as well).
+#if !defined(CRH_I8_STATIC)
+        int inext_l = 0;
+        if (lane == 0) {
+            const int m = atomicAdd(&next_m, 1);
+            const unsigned int j = (unsigned int)(m / WAVES), w = (unsigned int)(m % WAVES);
+            if (w == 0) {
+                const unsigned int c = gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&cslot[(j + 1) % 8], ((unsigned long long)(j + 1) << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned long long e;
+            while (((e = __hip_atomic_load(&cslot[j % 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) != j) __builtin_amdgcn_s_sleep(1);
+            const unsigned int c = (unsigned int)e;
+            inext_l = c > 0x7fffffffu / WAVES ? 0x7fffffff : (int)(c * WAVES + w);
+        }
+        const int inext = __builtin_amdgcn_readfirstlane(inext_l);
 #else
         const int inext = i + total;
 #endif

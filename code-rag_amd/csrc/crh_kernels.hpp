@@ -42,7 +42,7 @@ struct SearchStatus {
     unsigned long long candidates;
     unsigned int bar_a, bar_b;   // arrival counters of the two grid-wide waits of k_scan_fused (zeroed with the slot)
     unsigned int bar_timeout;    // set when one of those waits gave up (a workgroup never became resident): results are void
-    unsigned int pad_;
+    unsigned int next_chunk;     // k_scan_i8: tile chunks handed out so far beyond each workgroup's first (zeroed with the slot)
     unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
     unsigned int qsurv[kMaxQ];    // k_select split over several workgroups per query: survivors published so far ...
     unsigned int qdone[kMaxQ];    // ... and workgroups that have published (the last one ranks)
