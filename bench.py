@@ -38,7 +38,7 @@ _T0 = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-ALL_LEGS = ("filtered", "scan_bf16", "wide", "config5", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
+ALL_LEGS = ("filtered", "scan_bf16", "wide", "config5", "clustered", "anisotropic", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
 
 
 def log(msg: str) -> None:
@@ -92,7 +92,8 @@ def parse_args():
     ap.add_argument("--c2-parity-chunks", type=int, default=2000, help="chunks of the c2 leg's end-to-end recall subsample (per weight statistic)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rows per GPU (BASELINE C4a); strong: --rows in total, split over the ranks (C4b)")
-    ap.add_argument("--check-rows", type=int, default=200_000, help="rows of the parity subsample checked vs the oracle")
+    ap.add_argument("--check-rows", type=int, default=1_000_000,
+                    help="rows of the parity subsample checked vs the oracle (from 1M rows the sub-index is nominated from its int8 copy, like the timed corpus)")
     ap.add_argument("--legs", default=None, help="comma list of sub-records to run beside the headline "
                     f"({','.join(ALL_LEGS)}); default: all at N=1, config5+embed at N>1; 'none' = headline only")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of the filtered / f32_store / config5 legs")
@@ -231,30 +232,88 @@ def rehearse(args, json_fd) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ the measurement
-def build_corpus(torch, ffi, dev, rows, dtype, seed, check_rows, code_cols=1, stream=0, seed_tiles=0):
-    """Rows ~ N(0, I) generated on the device in blocks (never staged through host lists), normalised on insert; one
-    dictionary-coded payload column (`language`: 3 uniform codes) beside them, as every collection of the reference has
-    keyword payload indexes (embeddings/client.py:77-89).  Returns (index, head rows, head codes) -- the head is the
-    parity subsample."""
+CORPUS_KINDS = ("gaussian", "clustered", "anisotropic")
+
+
+def corpus_generator(torch, dev, kind, seed, D=768):
+    """Row blocks of one of the corpus kinds SURVEY 8(d) / the round-3 review name, generated on the device:
+    gaussian     rows ~ N(0, I) (the headline; scores ~ N(0, 1/D));
+    clustered    1000 unit centres + 0.7 * N(0, I)/sqrt(D) (SURVEY 8(d)'s secondary corpus); queries: a centre + the same noise;
+    anisotropic  encoder-like: x = c + a * P z / sqrt(r) + b * g / sqrt(D) with ONE shared unit direction c, a 64-dimensional
+                 noise subspace P (orthonormal) and a little isotropic noise, a^2 + b^2 = 0.352 -- the mean unit vector then
+                 has norm 1/sqrt(1.352) = 0.86 and a query's top-1 and top-100 of 10M rows lie ~0.03 apart, the statistics
+                 `c2.embedding_geometry` reports for encoder output; queries: fresh draws of the same model.
+    Returns (block(m) -> [m, D] f32 tensor, queries(n, seed) -> [n, D] f32 ndarray)."""
+    import numpy as np
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    if kind == "gaussian":
+        return (lambda m: torch.randn((m, D), generator=gen, device=dev, dtype=torch.float32),
+                lambda n, qseed: np.random.default_rng(qseed).standard_normal((n, D)).astype(np.float32))
+    if kind == "clustered":
+        centres = torch.randn((1000, D), generator=gen, device=dev)
+        centres /= centres.norm(dim=1, keepdim=True)
+
+        def block(m):
+            pick = torch.randint(0, 1000, (m,), generator=gen, device=dev)
+            return centres[pick] + 0.7 * torch.randn((m, D), generator=gen, device=dev) / (D ** 0.5)
+
+        def queries(n, qseed):
+            r = np.random.default_rng(qseed)
+            return (centres.cpu().numpy()[r.integers(0, 1000, n)] + 0.7 * r.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
+        return block, queries
+    if kind == "anisotropic":
+        r0 = np.random.default_rng(seed)
+        rank_, a2, b2 = 64, 0.302, 0.05
+        c = r0.standard_normal(D)
+        c /= np.linalg.norm(c)
+        P = np.linalg.qr(r0.standard_normal((D, rank_)))[0].astype(np.float32)            # [D, 64], orthonormal columns
+        c_d, P_d = torch.from_numpy(c.astype(np.float32)).to(dev), torch.from_numpy(P).to(dev)
+
+        def block(m):
+            z = torch.randn((m, rank_), generator=gen, device=dev)
+            g = torch.randn((m, D), generator=gen, device=dev)
+            return c_d[None, :] + (a2 / rank_) ** 0.5 * (z @ P_d.T) + (b2 / D) ** 0.5 * g
+
+        def queries(n, qseed):
+            r = np.random.default_rng(qseed)
+            return (c[None, :] + (a2 / rank_) ** 0.5 * (r.standard_normal((n, rank_)) @ P.T)
+                    + (b2 / D) ** 0.5 * r.standard_normal((n, D))).astype(np.float32)
+        return block, queries
+    raise ValueError(kind)
+
+
+def build_corpus(torch, ffi, dev, rows, dtype, seed, check_rows, code_cols=1, stream=0, seed_tiles=0, kind="gaussian"):
+    """Rows of `kind` (corpus_generator) generated on the device in blocks (never staged through host lists), normalised on
+    insert; one dictionary-coded payload column (`language`: 3 uniform codes) beside them, as every collection of the
+    reference has keyword payload indexes (embeddings/client.py:77-89).  Returns (index, head rows, head codes) -- the head
+    (the first check_rows rows) is the parity subsample."""
     D = 768
     idx = ffi.Index(D, dtype, capacity_rows=rows, n_code_cols=code_cols, device=dev.index)
     if seed_tiles:
         idx.set_tuning(seed_tiles=seed_tiles)
+    block_of, _ = corpus_generator(torch, dev, kind, seed, D)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    head = head_codes = None
+    gen.manual_seed(seed + 1)
+    heads, head_codes = [], []
+    kept = 0
     block = 500_000
     for r0 in range(0, rows, block):
         m = min(block, rows - r0)
-        xb = torch.randn((m, D), generator=gen, device=dev, dtype=torch.float32)
+        xb = block_of(m)
         cb = torch.randint(0, 3, (m, code_cols), generator=gen, device=dev, dtype=torch.int32) if code_cols else None
         idx.append(xb, codes=cb, stream=stream)
-        if r0 == 0:
-            head = xb[: min(check_rows, m)].cpu().numpy()
-            head_codes = cb[: min(check_rows, m)].cpu().numpy() if cb is not None else None
+        if kept < check_rows:
+            t = min(check_rows - kept, m)
+            heads.append(xb[:t].cpu().numpy())
+            if cb is not None:
+                head_codes.append(cb[:t].cpu().numpy())
+            kept += t
         torch.cuda.synchronize()
         del xb, cb
-    return idx, head, head_codes
+    import numpy as np
+    head = np.concatenate(heads) if heads else None
+    return idx, head, (np.concatenate(head_codes) if head_codes else None)
 
 
 NSLOTS = 4  # rotating output buffers
@@ -320,24 +379,30 @@ def scan_roofline(rows, D, scan_ms, launches, mode):
                           + "; every returned id and score: canonical f32 arithmetic on the stored rows"}
 
 
-def subsample_parity(np, ffi, orc, head, head_codes, qs, K, dtype, device, filters=None):
-    """HIP index over the first rows of the corpus vs the oracle on the same rows: ids and f32 score bits."""
+def subsample_parity(np, ffi, orc, head, head_codes, qs, K, dtype, device, filters=None, truth=True):
+    """HIP index over the first rows of the corpus vs the oracle on the same rows: ids and f32 score bits.  The record says
+    which scan nominated the rows of THIS check (`nomination` / `kernel`: from 1M rows up the library's default is the int8 copy,
+    the path of the 10M-row line) and what that search did (`search_stats`)."""
     bf16 = dtype == ffi.DTYPE_BF16
     ncols = 0 if head_codes is None else head_codes.shape[1]
     sub = ffi.Index(head.shape[1], dtype, capacity_rows=head.shape[0], n_code_cols=ncols, device=device)
     sub.append(head, codes=head_codes)
     gs, gr = sub.search(qs, K, filters=filters)
+    mode, st = sub.nomination(), sub.stats()
+    sub.close()
     kw = {"codes": head_codes, "filters": list(filters)} if filters else {}
     es, er = orc.cosine_search(head, qs, K, bf16=bf16, **kw)
-    ts, tr = orc.cosine_search(head, qs, K, bf16=False, **kw)
-    sub.close()
+    ts, tr = orc.cosine_search(head, qs, K, bf16=False, **kw) if truth else (None, None)
 
     def recall(a, b):
         return float(np.mean([len(set(x[x >= 0]) & set(y[y >= 0])) / max(1, int((y >= 0).sum())) for x, y in zip(a, b)]))
-    return {"rows": int(head.shape[0]), "ids_bit_exact": bool(np.array_equal(gr, er)),
+    return {"rows": int(head.shape[0]), "queries": int(qs.shape[0]), "ids_bit_exact": bool(np.array_equal(gr, er)),
             "scores_bit_exact": bool(np.array_equal(gs.view(np.uint32), es.view(np.uint32))),
-            "recall_at_k_vs_oracle_same_precision": recall(gr, er), "recall_at_k_vs_f32_truth": recall(gr, tr),
-            "max_abs_score_error_vs_f32_truth": float(np.max(np.abs(np.sort(gs, axis=1) - np.sort(ts, axis=1))))}
+            "nomination": {2: "int8 copy", 1: "bf16 tiles, one launch", 0: "bf16 tiles, three launches"}.get(mode, str(mode)),
+            "kernel": scan_kernel_name(head.shape[1], mode),
+            "search_stats": {k: st[k] for k in ("candidates", "max_query_cands", "fallback_used") if k in st},
+            "recall_at_k_vs_oracle_same_precision": recall(gr, er), "recall_at_k_vs_f32_truth": recall(gr, tr) if truth else None,
+            "max_abs_score_error_vs_f32_truth": float(np.max(np.abs(np.sort(gs, axis=1) - np.sort(ts, axis=1)))) if truth else None}
 
 
 def run(args, json_fd) -> None:
@@ -375,7 +440,7 @@ def run(args, json_fd) -> None:
     if args.no_cpu_baseline or world > 1:
         legs -= {"cpu"}
     if world > 1:
-        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "scan_bf16", "wide"}      # one-GPU verification legs
+        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "scan_bf16", "wide", "clustered", "anisotropic"}      # one-GPU verification legs
 
     D, N, B, K = 768, args.rows, args.queries, args.k
     if args.scaling == "strong":
@@ -495,6 +560,7 @@ def run(args, json_fd) -> None:
     scan_ms = scan_ms_total / max(1, scan_launches)
     roof = scan_roofline(N, D, scan_ms, scan_launches, nom_mode)
     roof["traffic"] = traffic
+    roof["whole_step_frac"] = roof["algorithmic_bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS   # the whole step on the pass's bytes
     roof["traffic_source"] = "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None
     out = {
         "metric": "top-k queries/s over 10Mx768 (cosine top-100, batch 64)",
@@ -549,7 +615,8 @@ def run(args, json_fd) -> None:
                "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
                "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], idx.nomination()), "search_stats": r["stats"]}
         if orc is not None:
-            res["parity"] = subsample_parity(np, ffi, orc, head, head_codes, qs, K, dtype, local_rank, filters=[(0, 1)])
+            m = min(200_000, head.shape[0])
+            res["parity"] = subsample_parity(np, ffi, orc, head[:m], head_codes[:m], qs, K, dtype, local_rank, filters=[(0, 1)])
         log(f"filtered: {r['ms_per_step']:.3f} ms/step")
         return res
 
@@ -566,10 +633,56 @@ def run(args, json_fd) -> None:
             idx.set_nomination(ffi.NOMINATE_INT8)
         same = bool(torch.equal(r["rows"], headline_rows - row_base) and torch.equal(r["scores"].view(torch.int32), headline_scores.view(torch.int32)))
         log(f"scan_bf16: {r['ms_per_step']:.3f} ms/step")
+        roof16 = scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode)
+        # SURVEY 8(d)'s own accounting (N x 768 x 2 bytes per launch, the bf16 brute-force pass north_star's ">= 70 % of the HBM
+        # roofline" speaks of) sits in the HEADLINE's roofline block beside the int8 pass's figure on the bytes IT reads
+        out["roofline"]["bf16_scan"] = {"kernel": roof16["kernel"], "kernel_ms": roof16["kernel_ms"], "achieved": roof16["achieved"], "frac": roof16["frac"],
+                                        "algorithmic_bytes_per_launch": roof16["algorithmic_bytes_per_launch"], "ms_per_step": r["ms_per_step"],
+                                        "whole_step_frac": roof16["algorithmic_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "identical_to_headline": same,
+                                        "what": "the same batch on the same index with the int8 copy switched off (crh_index_set_nomination): "
+                                                "the one-launch scan over the bf16 tiles, 2 bytes per element"}
         return {"workload": f"{N}x{D} {args.dtype}, batch-{B} top-{K}, nominated from the bf16 tiles", "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7),
                 "unit": out["unit"], "ms_per_step": r["ms_per_step"], "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
-                "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode), "search_stats": r["stats"],
+                "roofline": roof16, "search_stats": r["stats"],
                 "identical_to_headline": same}
+
+    def corpus_kind_leg(kind):
+        """The headline batch on a corpus that is NOT N(0, I): `clustered` (SURVEY 8(d)'s secondary corpus) and `anisotropic`
+        (encoder-like: one shared direction, low-rank noise -- corpus_generator).  What the int8 intervals nominate depends on the
+        data: each record carries `search_stats` (candidates per query, fallbacks), the roofline on the bytes the pass read, the
+        geometry of the corpus, and parity of a 1M-row sub-index (int8 copy live there too) against the oracle."""
+        def run_leg():
+            kidx, khead, kcodes = build_corpus(torch, ffi, dev, N, dtype, 777 + rank, args.check_rows, 1, stream, args.seed_tiles, kind=kind)
+            try:
+                _, queries_of = corpus_generator(torch, dev, kind, 777 + rank, D)
+                kq = queries_of(B, 7)
+                kqd = torch.from_numpy(kq).to(dev)
+                r = timed_search(torch, kidx, kqd, K, None, args.sub_steps, 3, stream)
+                mode = kidx.nomination()
+                roof_k = scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode)
+                roof_k["whole_step_frac"] = roof_k["algorithmic_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                st = r["stats"]
+                gs = r["scores"].cpu().numpy()
+                res = {"workload": f"{N}x{D} {args.dtype} {kind} corpus, batch-{B} top-{K}", "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7),
+                       "unit": out["unit"], "ms_per_step": r["ms_per_step"], "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
+                       "roofline": roof_k, "search_stats": st,
+                       "candidates_per_query_and_batch": st["candidates"] / max(1, st["batches"]) / B if "batches" in st else None,
+                       "fallback_used": st.get("fallback_used"),
+                       "geometry": {"top1_score_median": float(np.median(gs[:, 0])), "topk_score_median": float(np.median(gs[:, K - 1])),
+                                    "top1_minus_topk_median": float(np.median(gs[:, 0] - gs[:, K - 1]))}}
+                if khead is not None:
+                    hn = khead[:100_000] / np.linalg.norm(khead[:100_000], axis=1, keepdims=True)
+                    res["geometry"]["norm_of_mean_unit_vector"] = float(np.linalg.norm(hn.mean(0)))
+                if orc is not None and khead is not None:
+                    res["parity"] = subsample_parity(np, ffi, orc, khead, kcodes, kq, K, dtype, local_rank, truth=False)
+                log(f"{kind}: {r['ms_per_step']:.3f} ms/step, kernel {r['scan_ms']:.3f} ms, candidates/query {res['candidates_per_query_and_batch']}, "
+                    f"fallback {st.get('fallback_used')}")
+                return res
+            finally:
+                kidx.close()
+                torch.cuda.empty_cache()
+        return run_leg
 
     def wide_leg():
         """One search call with 512 queries: two passes of k_scan_wide (256 queries share a corpus pass, query fragments in
@@ -612,7 +725,7 @@ def run(args, json_fd) -> None:
     torch.cuda.empty_cache()
 
     def f32_leg():
-        f32, h32, hc32 = build_corpus(torch, ffi, dev, N, ffi.DTYPE_F32, 20251226 + rank, args.check_rows, 1, stream, args.seed_tiles)
+        f32, h32, hc32 = build_corpus(torch, ffi, dev, N, ffi.DTYPE_F32, 20251226 + rank, min(args.check_rows, 200_000), 1, stream, args.seed_tiles)
         try:
             r = timed_search(torch, f32, qd, K, None, args.sub_steps, 3, stream)
             a_, b_ = r["rows"].cpu().numpy(), (headline_rows - row_base).cpu().numpy()
@@ -631,6 +744,8 @@ def run(args, json_fd) -> None:
             f32.close()
             torch.cuda.empty_cache()
 
+    leg("clustered", corpus_kind_leg("clustered"))
+    leg("anisotropic", corpus_kind_leg("anisotropic"))
     leg("f32_store", f32_leg)
     if args.embed_chunks <= 0:
         legs.discard("embed")
