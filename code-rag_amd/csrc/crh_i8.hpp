@@ -21,6 +21,13 @@
 // are simply nominated more often; when the candidate buffers overflow the host re-runs the batch on the bf16 scan
 // (finish_pending) and, after three overflows in a row, rests the int8 copy of that index for 4096 batches.
 //
+// ROW-MAJOR ROWS (round 4).  The selection behind this scan fetches SINGLE rows: ~800 survivors per query and 10M rows.  In the
+// tiled image a row is 48 runs of 32 bytes, 1 KiB apart -- 48 HBM lines of 128 bytes for 1536 useful bytes, and the fetch rate of
+// one CU (~24 GB/s of lines) is what bounded k_select (stamps: 50 us for 208 rows per workgroup, whatever the arithmetic).  An index
+// that keeps the int8 copy therefore also keeps its bf16 rows ROW-MAJOR ([rows][dim] bf16, +2 bytes per element), written by
+// k_requant_i8 from the tiles it reads anyway: a row is then 12 full lines.  Only single-row reads use it (partial_dot8,
+// canonical_dot_rows); without it (no memory, an f32 store -- whose f32 master is row-major already) they read the tiles.
+//
 // Layout of the copy: tile = 32 rows; piece p of a tile = 1 KiB = elements [32p, 32p + 32) of its 32 rows as ONE MFMA operand
 // (lane l: row l & 31, elements 32p + 16 (l >> 5) .. + 15, one byte each).  Pieces of a tile are consecutive: D / 32 KiB per tile.
 // The copy is derived from the stored rows (k_requant_i8: the bf16 tiles, or the f32 master of an f32 store), never stored in
@@ -44,7 +51,7 @@ constexpr float kI8QueryLevels = 16256.0f;   // 127 * 128: Q = 128 H + L with H 
 template <bool F32>
 __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt, const float *__restrict__ xf32, u32x4 *__restrict__ x8,
                                                    float *__restrict__ srow, unsigned int *__restrict__ dn_bits, int64_t t0, int ksteps,
-                                                   int64_t count)
+                                                   int64_t count, u32x4 *__restrict__ xrow)
 {
     const int64_t tile = t0 + blockIdx.x;
     const int lane = threadIdx.x, row = lane & 31, hh = lane >> 5;
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
     const int ks8 = ksteps >> 1, dim = ksteps * 16;
     const float4 *fr = reinterpret_cast<const float4 *>(xf32 + ((size_t)tile * 32 + row) * dim);   // (F32 only)
     // the lane's 16 elements of piece p: elements [32p + 16hh, + 16) of its row
-    auto fetch16 = [&](int p, float (&v)[16]) {
+    auto fetch16 = [&](int p, float (&v)[16], bool copy_row) {
         if (!live) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = 0.f;
@@ -69,6 +76,11 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
         } else {
             const int s = 2 * p + hh;                    // bf16 piece holding those elements for the tile's 32 rows
             const u32x4 a = tp[piece_off(s) + piece_slot(0, row)], b = tp[piece_off(s) + piece_slot(1, row)];
+            if (copy_row && xrow != nullptr) {           // the row-major side copy (ROW-MAJOR ROWS below): 32 bytes of this lane's row
+                u32x4 *dst = xrow + ((size_t)tile * 32 + row) * (size_t)(ksteps * 2) + 2 * s;
+                dst[0] = a;
+                dst[1] = b;
+            }
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
     float m = 0.f;
     for (int p = 0; p < ks8; ++p) {
         float v[16];
-        fetch16(p, v);
+        fetch16(p, v, true);
 #pragma unroll
         for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(v[j]));
     }
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
     float dsq = 0.f;
     for (int p = 0; p < ks8; ++p) {
         float v[16];
-        fetch16(p, v);
+        fetch16(p, v, false);
         uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -191,9 +203,10 @@ template <int KS8, int WAVES, int RING, int QB>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const u32x4 *__restrict__ x8, const float *__restrict__ srow, const unsigned int *__restrict__ dn_bits,
     const u32x4 *__restrict__ qfrag8, const float *__restrict__ qpar, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
-    float *__restrict__ gmax, float *__restrict__ tau_g, int k, float c_abs, float sqrt_dim, int nq, u32x4 *__restrict__ wave_lists,
+    uint32_t *__restrict__ gkey, float *__restrict__ tau_g, int k, float c_abs, float sqrt_dim, int nq, u32x4 *__restrict__ wave_lists,
     int wave_cap, unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, float *__restrict__ qlo, int qcap,
-    SearchStatus *__restrict__ status, int wait_extra)
+    SearchStatus *__restrict__ status, int wait_extra, const u32x4 *__restrict__ xt, const float *__restrict__ xf32,
+    const float *__restrict__ qn, const u32x4 *__restrict__ xrow, unsigned int wait_ticks)
 {
     static_assert(KS8 % RING == 0, "the ring must divide the pieces of a tile (slot s % RING holds piece s of every tile)");
     constexpr int NT = WAVES * 64, NQS = QB * 32, NB = NT < 1024 ? NT : 1024;
@@ -234,8 +247,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         const int qi = b * 32 + (lane & 31);
         const float s_q = qpar[qi * 4 + 0], Qn = qpar[qi * 4 + 1], gn = qpar[qi * 4 + 2];
         sq[b] = s_q;
-        // + 128: the f32 evaluation of 128 * dotH + dotL (both exact integers below 2^24) rounds once, by <= 2^30 * 2^-24 = 64
-        Bq[b] = (dn * (Qn + gn) + 127.0f * sqrt_dim * gn) * 1.0001f + 128.0f;
+        // + kDotRound: what the f32 evaluation of f = 128 * dotH + dotL and of f + B_q can lose.  |dotH| <= 127 * 127 * D and
+        // |dotL| <= 127 * 64 * D.  D <= 1024: both are exact in f32 (< 2^24), |f| < 2^31, the fma and the sum round once each by
+        // <= 64.  D = 1536: |dotH| reaches 24.8M > 2^24, so its conversion to f32 may be off by 1 (x 128), and |f| reaches 3.2e9 in
+        // [2^31, 2^32), where the two roundings are <= 128 each: 384 in all.  (Round 3 wrote 128 for every width; only saturated
+        // rows against a saturated query -- every element at +-max -- come near these magnitudes: tests/test_search_gpu.py,
+        // test_saturated_rows_and_queries.)
+        constexpr float kDotRound = KS8 * 32 <= 1024 ? 128.0f : 512.0f;
+        static_assert(KS8 * 32 <= 2048, "beyond D = 2048 |f| passes 2^32 and dotH 2^25: the allowance has to be derived again");
+        Bq[b] = (dn * (Qn + gn) + 127.0f * sqrt_dim * gn) * 1.0001f + kDotRound;
         if (wave == 0 && lane < 32) hwf[qi] = s_q * Bq[b];
     }
 
@@ -365,41 +385,117 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             intervals(acc, sr, hi);
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
-                float m = -INFINITY;
+                // (ord(lower end) with its five low bits given to the row's number inside the tile: rounded DOWN, still a lower
+                // end, and the threshold phase learns WHICH row of the tile it belongs to; 0 = no valid row)
+                uint32_t m = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    m = fmaxf(m, ((vmask >> row) & 1u) ? lower_end(hi[b][r], sr, b, r) : -INFINITY);
+                    const uint32_t key = (ord_f32(lower_end(hi[b][r], sr, b, r)) & ~31u) | (uint32_t)row;
+                    m = max(m, ((vmask >> row) & 1u) ? key : 0u);
                 }
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (h == 0) gmax[(size_t)(b * 32 + lane) * G + g] = m;
+                m = max(m, (uint32_t)__shfl_xor((int)m, 32));
+                if (h == 0) gkey[(size_t)(b * 32 + lane) * G + g] = m;
             }
             g = gn_;
         }
         if (gw >= G && gw < ntiles) prime(tile_ptr(gw));   // waves without a sample tile: start the main stream now
     }
     CRH_STAMP(2);
-    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
+    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status, wait_ticks);
     CRH_STAMP(3);
 
     // ---- 2. thresholds: workgroup q owns query q (no margin: the intervals carry it)
+    // The k tiles with the largest lower ends name k distinct rows; their scores are then worked out from the STORED rows (any
+    // summation order: within c_abs of the canonical score) and the k-th largest of those, minus c_abs, is the threshold -- a
+    // lower bound of the true k-th score that no longer carries the width of an int8 interval (the k-th largest LOWER END, the
+    // threshold of round 3, sits a whole half-width below it: 21 k -> ~9 k candidates per query at 10M Gaussian rows).
+    constexpr unsigned int kFloorKey = 0x007fffffu;       // ord(-inf) | 31: keys at or below it belong to no valid row
+    constexpr int SELCAP = 384;                           // k <= 256 (kI8MaxK) + room for equal keys
+    static_assert(NB + 256 + 2 * (NT / 64) + 8 >= 2 * SELCAP, "sel / selv overlay the scratch of wg_kth_largest_fast");
+    static_assert((NT / 64) * 256 >= KS8 * 32, "the canonical query overlays the radix histograms");
     for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
         float t = -INFINITY;
         if (q >= nq) {
             t = INFINITY;
         } else if (G >= k) {
-            for (int i = tid; i < G; i += NT) col[i] = ord_f32(gmax[(size_t)q * G + i]);
+            constexpr int DIM = KS8 * 32;
+            float qreg[(DIM + NT - 1) / NT];               // the canonical query: requested now, parked in LDS after the selection
+#pragma unroll
+            for (int j = 0; j < (DIM + NT - 1) / NT; ++j) qreg[j] = (tid + j * NT < DIM) ? qn[(size_t)q * DIM + tid + j * NT] : 0.f;
+            {   // the query's G keys: every thread's loads requested together (one round trip, not G / NT of them)
+                constexpr int PER = kI8SampleTiles / NT;
+                uint32_t kreg[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) kreg[j] = (tid + j * NT < G) ? gkey[(size_t)q * G + tid + j * NT] : 0u;
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (tid + j * NT < G) col[tid + j * NT] = kreg[j];
+            }
             __syncthreads();
+            CRH_TAU_STAMP(8);
             const uint32_t key = wg_kth_largest_fast<NT, NB, 256>([&](unsigned int i) { return col[i]; }, (unsigned int)G, (unsigned int)k,
-                                                                  ord_f32(-INFINITY), fast, hist, bcast);
-            t = unord_f32(key);
+                                                                  kFloorKey, fast, hist, bcast);
+            __syncthreads();
+            CRH_TAU_STAMP(9);
+            if (key > kFloorKey) {
+                t = unord_f32(key & ~31u);
+                unsigned int *sel = fast;                                  // [SELCAP] sample tile << 5 | row inside it
+                float *selv = reinterpret_cast<float *>(fast + SELCAP);    // [SELCAP] score of that row
+                float *qv = reinterpret_cast<float *>(hist);               // [dim] the canonical query
+                if (tid == 0) bcast[0] = 0u;
+#pragma unroll
+                for (int j = 0; j < (DIM + NT - 1) / NT; ++j)
+                    if (tid + j * NT < DIM) qv[tid + j * NT] = qreg[j];
+                __syncthreads();
+                for (int i = tid; i < G; i += NT) {
+                    const uint32_t c = col[i];
+                    if (c >= key) {
+                        const unsigned int p = atomicAdd(&bcast[0], 1u);
+                        if (p < (unsigned int)SELCAP) sel[p] = ((uint32_t)i << 5) | (c & 31u);
+                    }
+                }
+                __syncthreads();
+                CRH_TAU_STAMP(10);
+                const unsigned int nsel = bcast[0];
+                if (nsel <= (unsigned int)SELCAP) {                        // (more: masses of equal keys -- the lower-end threshold stands)
+                    // eight lanes per row (partial_dot8): all of a row's bytes are requested at once
+                    const int sub = tid & 7;
+                    for (unsigned int r0 = 0; r0 < nsel; r0 += NT / 8) {
+                        const unsigned int r = r0 + (unsigned int)(tid >> 3);
+                        float acc = 0.f;
+                        if (r < nsel) {
+                            const uint32_t e = sel[r];
+                            acc = partial_dot8<6>(xt, xf32, xrow, DIM, KS8 * 2, (uint32_t)((e >> 5) * (uint32_t)S * 32u + (e & 31u)), qv, sub);
+                        }
+                        acc = sum8(acc);
+                        if (r < nsel && sub == 0) selv[r] = acc;
+                    }
+                    __syncthreads();
+                    CRH_TAU_STAMP(11);
+                    // the k-th largest of the nsel >= k scores, by counting
+                    if ((unsigned int)tid < nsel) {
+                        const float v = selv[tid];
+                        unsigned int gt = 0u, ge = 0u;
+                        for (unsigned int j = 0; j < nsel; ++j) {
+                            const float o = selv[j];
+                            gt += o > v ? 1u : 0u;
+                            ge += o >= v ? 1u : 0u;
+                        }
+                        if (gt < (unsigned int)k && (unsigned int)k <= ge) bcast[1] = f32_bits(v);
+                    }
+                    __syncthreads();
+                    CRH_TAU_STAMP(12);
+                    t = fmaxf(t, bits_f32(bcast[1]) - c_abs);
+                }
+            }
             __syncthreads();
         }
         if (tid == 0) tau_g[q] = t;
     }
     const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
     CRH_STAMP(4);
-    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status, wait_ticks);
     CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
     __syncthreads();

@@ -5,6 +5,7 @@
 // One handle = one collection shard on one GPU.  gfx950 only; no fallback path exists:
 // if HIP or the device is missing every entry point fails with CRH_E_HIP / CRH_E_NODEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +48,7 @@ struct Pending {
     float *out_s;
     int64_t *out_r;
     int slot;
-    bool used_i8;   // the batch was nominated from the int8 copy (an overflow then sends it to the bf16 scan, not to bigger buffers)
+    int path;       // how enqueue_batch nominated the batch's rows: CRH_NOMINATE_INT8 / _BF16 (one launch) / _BF16_3 (three launches, wide scan)
 };
 
 }  // namespace
@@ -57,12 +58,18 @@ struct crh_index {
     int batch_q = 64;  // queries per k_scan pass: 64, or 32 when the 64-query image would not fit LDS (dim 1536)
     bool wide_ok = false;  // k_scan_wide (up to 256 queries per corpus pass, query fragments in registers) exists for this dim
     bool fused_scan = true;   // <= batch_q queries: seed scan + threshold + main scan in one launch (CODERAG_HIP_FUSED_SCAN=0: three)
-    int fused_cooldown = 0;   // batches still to run in the three-launch form after a grid-wide wait timed out (then the one-launch
-                              // forms get another chance: the cause -- another stream's kernels holding CUs -- is usually transient)
+    // After a grid-wide wait timed out (another stream's kernels held CUs) the index runs the three-launch form for a WINDOW OF
+    // TIME, not a number of batches: 0.2 s, doubled by every further time-out up to 5 s, back to 0.2 s once a one-launch batch
+    // has gone through (round 3 rested 1024 batches: 2.5 s of queries at the bf16 rate for what is usually a transient cause).
+    std::chrono::steady_clock::time_point fused_rest_until{};
+    double fused_rest_s = 0.2;
+    bool fused_resting() const { return std::chrono::steady_clock::now() < fused_rest_until; }
     // int8 nomination copy (crh_i8.hpp): derived from xt, brought up to date before a scan (i8_sync); tiles >= i8_dirty_from are stale
     bool i8 = false;          // <= batch_q queries are nominated from the copy (dim 384 / 768 / 1536; CODERAG_HIP_I8=0: never)
     u32x4 *x8 = nullptr;
     float *srow = nullptr;
+    u32x4 *xrow = nullptr;    // row-major bf16 rows beside the copy (bf16 stores; crh_i8.hpp, ROW-MAJOR ROWS): what k_select's single-row reads use
+    bool want_xrow = true;    // (CODERAG_HIP_ROWMAJOR=0: never -- the single-row reads then go to the tiles, as in round 3)
     unsigned int *i8stat = nullptr;
     int64_t x8_cap_tiles = 0, i8_dirty_from = 0;
     int i8_strikes = 0;       // consecutive int8-nominated batches whose candidate buffers overflowed (3: the copy is left unused ...
@@ -269,13 +276,24 @@ int launch_scan(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t s
     return CRH_OK;
 }
 
+// What a one-launch scan may spend in ONE grid-wide wait, in 100 MHz ticks: eight times the time its pass over `bytes` should take
+// (priced at 4 TB/s, two thirds of what the scans reach), at least 2 ms.  A wait ends when every workgroup has become resident and
+// done its share of the phase before it; on an otherwise idle device that is microseconds, beside another stream's kernels it is
+// that kernel's remaining time -- and beyond this bound the three-launch form, which needs nobody resident, is the better answer.
+unsigned int wait_ticks_for(double bytes)
+{
+    const double ticks = 8.0 * bytes / 4.0e12 * 1.0e8;
+    return (unsigned int)std::min(4.0e9, std::max(2.0e5, ticks));
+}
+
 // seed scan + threshold + main scan in one launch (k_scan_fused): <= batch_q queries, the default sample size
 int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int ntiles, int G, int S, int k, float margin,
                       int nq, int wave_cap, int qcap, SearchStatus *stt)
 {
 #define CRH_FUSED(KS, QB)                                                                                                          \
     hipLaunchKernelGGL((k_scan_fused<KS, kWaves, kRing, QB>), dim3(blocks), dim3(kWaves * 64), 0, st, h->xt, w.qfrag, mask, ntiles, G, S, \
-                       w.gmax, w.tau, k, margin, nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt, h->force_fallback == 2 ? 1 : 0)
+                       w.gmax, w.tau, k, margin, nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, qcap, stt, h->force_fallback == 2 ? 1 : 0, \
+                       wait_ticks_for((double)ntiles * h->ksteps * 1024.0))
     switch (h->ksteps) {
     case 24: CRH_FUSED(24, 2); break;
     case 48: CRH_FUSED(48, 2); break;
@@ -291,7 +309,7 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 constexpr int kI8MaxK = 256;   // beyond this k the threshold sits so low that the int8 intervals nominate several 100 k rows per query
 bool i8_use(const crh_index *h, int nq, int k)
 {
-    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_cooldown == 0 && nq <= h->batch_q && h->fused_scan && h->fused_cooldown == 0 &&
+    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_cooldown == 0 && nq <= h->batch_q && h->fused_scan && !h->fused_resting() &&
            (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
@@ -303,6 +321,7 @@ int i8_alloc(crh_index *h)
     const int ks8 = h->dim / 32;
     dev_free(h->x8);
     dev_free(h->srow);
+    dev_free(h->xrow);
     h->x8_cap_tiles = 0;
     bool ok = hipMalloc(reinterpret_cast<void **>(&h->x8), (size_t)h->cap_tiles * ks8 * 1024) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&h->srow), (size_t)h->cap_tiles * 32 * sizeof(float)) == hipSuccess;
@@ -314,6 +333,12 @@ int i8_alloc(crh_index *h)
         dev_free(h->srow);
         h->i8 = false;
         return CRH_OK;
+    }
+    // the row-major rows are an accelerator of the selection step only: no memory for them -> the tiles are read instead
+    if (h->want_xrow && h->dtype == CRH_DTYPE_BF16 &&
+        hipMalloc(reinterpret_cast<void **>(&h->xrow), (size_t)h->cap_tiles * 32 * h->dim * 2) != hipSuccess) {
+        (void)hipGetLastError();
+        h->xrow = nullptr;
     }
     h->x8_cap_tiles = h->cap_tiles;
     h->i8_dirty_from = 0;
@@ -329,10 +354,10 @@ int i8_sync(crh_index *h, hipStream_t st)
     if (h->i8_dirty_from < ntiles) {
         if (h->dtype == CRH_DTYPE_F32)
             hipLaunchKernelGGL(k_requant_i8<true>, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->xf32, h->x8, h->srow,
-                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count);
+                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count, (u32x4 *)nullptr);
         else
             hipLaunchKernelGGL(k_requant_i8<false>, dim3((unsigned)(ntiles - h->i8_dirty_from)), dim3(64), 0, st, h->xt, h->xf32, h->x8, h->srow,
-                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count);
+                               h->i8stat, h->i8_dirty_from, h->ksteps, h->count, h->xrow);
         CRH_HIP(hipGetLastError());
         h->i8_dirty_from = ntiles;
     }
@@ -344,8 +369,10 @@ int launch_scan_i8(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_
 {
 #define CRH_I8(KS8, RING, QB)                                                                                                          \
     hipLaunchKernelGGL((k_scan_i8<KS8, kI8Waves, RING, QB>), dim3(blocks), dim3(kI8Waves * 64), 0, st, h->x8, h->srow, h->i8stat, w.qfrag8, \
-                       w.qpar, mask, ntiles, G, S, w.gmax, w.tau, k, c_abs, sqrtf((float)h->dim), nq, w.wave_lists, wave_cap, stt->qcount,     \
-                       w.qlist, w.qlo, qcap, stt, h->force_fallback == 2 ? 1 : 0)
+                       w.qpar, mask, ntiles, G, S, reinterpret_cast<uint32_t *>(w.gmax), w.tau, k, c_abs, sqrtf((float)h->dim), nq, w.wave_lists,    \
+                       wave_cap, stt->qcount, w.qlist, w.qlo, qcap, stt, h->force_fallback == 2 ? 1 : 0, h->xt,                                \
+                       h->dtype == CRH_DTYPE_F32 ? h->xf32 : (const float *)nullptr, w.qn, h->xrow,                                             \
+                       wait_ticks_for((double)ntiles * (h->dim / 32) * 1024.0))
     switch (h->dim) {
     case 384: CRH_I8(12, 12, 2); break;
     case 768: CRH_I8(24, kI8Ring, 2); break;
@@ -378,8 +405,9 @@ int launch_scan_wide(crh_index *h, crh_index::Workspace &w, hipStream_t st, cons
 
 // one batch (<= batch_q queries through k_scan, or up to kWideQ through k_scan_wide), everything enqueued on `st`
 int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int nq, int k, const uint32_t *mask, int64_t row_base, float *out_s,
-                  int64_t *out_r, int slot, hipStream_t st)
+                  int64_t *out_r, int slot, hipStream_t st, int *path_out)
 {
+    *path_out = CRH_NOMINATE_BF16_3;
     const int64_t ntiles = ceil_div(h->count, kTileRows);
     if (ntiles == 0) {
         CRH_HIP(hipMemsetAsync(h->status + slot, 0, sizeof(SearchStatus), st));
@@ -419,24 +447,26 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
         CRH_TRY(launch_scan_i8(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
+        // (k_select's margin behind this scan: twice what separates a row's score summed in any order from its canonical score)
         if (h->dtype == CRH_DTYPE_F32)
             hipLaunchKernelGGL((k_select<true, true>), dim3(nq, kI8SelectParts), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.skeys2, w.qn, h->xt,
-                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+                               h->xf32, h->dim, h->ksteps, k, 2.f * c_abs, row_base, out_s, out_r, stt, (const u32x4 *)nullptr);
         else
             hipLaunchKernelGGL((k_select<false, true>), dim3(nq, kI8SelectParts), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.skeys2, w.qn, h->xt,
-                               h->xf32, h->dim, h->ksteps, k, margin, row_base, out_s, out_r, stt);
+                               h->xf32, h->dim, h->ksteps, k, 2.f * c_abs, row_base, out_s, out_r, stt, h->xrow);
         CRH_HIP(hipGetLastError());
         h->stats.rows += h->count;
         h->stats.tiles += ntiles;
         h->stats.seed_tiles += G8;
         h->stats.batches += 1;
+        *path_out = CRH_NOMINATE_INT8;
         return CRH_OK;
     }
 
     // <= batch_q queries at the default sample size: seed scan, threshold and main scan are ONE launch (k_scan_fused: every wave's
     // first tile is its sample tile, two grid-wide waits, the corpus read once).  The whole grid must be resident for those
     // waits: it is never larger than the CU count and a workgroup's LDS footprint leaves room for one per CU.
-    if (!wide && h->fused_scan && h->fused_cooldown == 0 && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
+    if (!wide && h->fused_scan && !h->fused_resting() && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64) {
         if (h->i8_cooldown > 0 && !h->i8_suppress) h->i8_cooldown -= 1;
         const int blocks = scan_blocks(h, ntiles);
         const int waves = blocks * kWaves;
@@ -456,9 +486,9 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         h->stats.tiles += ntiles;
         h->stats.seed_tiles += Gf;
         h->stats.batches += 1;
+        *path_out = CRH_NOMINATE_BF16;
         return CRH_OK;
     }
-    if (h->fused_cooldown > 0) h->fused_cooldown -= 1;
     if (!wide && h->i8_cooldown > 0 && !h->i8_suppress) h->i8_cooldown -= 1;
     const int G = (int)std::min<int64_t>(h->seed_tiles, ntiles);
     const int stride = (int)(ntiles / G);
@@ -516,39 +546,59 @@ int finish_pending(crh_index *h, hipStream_t st)
             }
         }
         int attempts = 0;
-        bool via_i8 = p.used_i8;
-        if (via_i8 && !(s.bar_timeout || s.wave_overflow || s.q_overflow)) h->i8_strikes = 0;
+        int path = p.path;
+        bool i8_regrown = false, no_i8 = false;   // no_i8: this batch has been sent to the bf16 scan -- for ALL its remaining attempts
+        if (!(s.bar_timeout || s.wave_overflow || s.q_overflow)) {
+            if (path == CRH_NOMINATE_INT8) h->i8_strikes = 0;
+            if (path != CRH_NOMINATE_BF16_3) h->fused_rest_s = 0.2;   // a one-launch batch went through: the next time-out rests the short window again
+        }
         while (s.bar_timeout || s.wave_overflow || s.q_overflow) {
             if (++attempts > 6) return fail(CRH_E_INTERNAL, "candidate buffers still overflow after %d regrowths", attempts - 1);
+            int wc = w.ws_wave_cap, qc = w.ws_qcap;
             if (s.bar_timeout) {
-                // A grid-wide wait of the one-launch scan gave up: some workgroup was not resident for ~0.5 s (other streams'
-                // kernels holding CUs).  The batch's results are void; this index goes to the three-launch form, which needs no
-                // co-residency, for this batch (run again) and the next 1024.
-                h->fused_cooldown = 1024;
+                // A grid-wide wait of the one-launch scan gave up: some workgroup was not resident within the launch's bound (other
+                // streams' kernels holding CUs).  The batch's results are void and its counts mean nothing (the thresholds were never
+                // agreed on): the buffers stay as they are, the batch is run again in the three-launch form, which needs no
+                // co-residency, and the index stays on that form for a window of time (crh_index::fused_rest_until).
+                h->fused_rest_until = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                                            std::chrono::duration<double>(h->fused_rest_s));
+                h->fused_rest_s = std::min(5.0, h->fused_rest_s * 2.0);
                 h->stats.fallback_used |= 2;
-            } else if (via_i8) {
-                // the int8 intervals of this data / this k are too wide for the candidate buffers: the batch goes to the bf16 scan
-                // (whose buffers regrow if they must); three such batches in a row and the copy is left unused
-                h->i8_strikes += 1;
-                if (h->i8_strikes >= 3) {
-                    h->i8_strikes = 2;
-                    h->i8_cooldown = 4096;
+            } else if (path == CRH_NOMINATE_INT8) {
+                // The int8 intervals of this data / this k nominated more rows than the buffers hold.  The true counts are known:
+                // when they are moderate (at most 2 % of the rows per query: beyond that the selection behind the scan costs more
+                // than the half pass it saves) the buffers grow to them ONCE and the batch runs again from the copy; otherwise,
+                // or when that was not enough, the batch goes to the bf16 scan (whose buffers regrow if they must), and three such
+                // batches in a row rest the copy for 4096 batches.
+                const int64_t need_q = next_pow2((int64_t)s.max_qcount), need_w = next_pow2((int64_t)s.max_wave_cnt) / (kWaves / kI8Waves);   // (an int8 wave's list is kWaves / kI8Waves x wave_cap entries)
+                const bool moderate = h->force_fallback != 3 && (int64_t)s.max_qcount <= std::max<int64_t>(h->count / 50, 4096) &&
+                                      (int64_t)kWideQ * need_q * 16 * 2 <= kWorkspaceBudget / 4;
+                if (!i8_regrown && moderate) {
+                    i8_regrown = true;
+                    h->stats.fallback_used |= 1;
+                    wc = std::max(wc, (int)std::min<int64_t>(need_w, 1 << 20));
+                    qc = std::max(qc, (int)need_q);
+                    h->qcap = std::max(h->qcap, qc);          // (the data will not change its mind: later batches start from here)
+                    h->wave_cap = std::max(h->wave_cap, wc);
+                } else {
+                    h->i8_strikes += 1;
+                    if (h->i8_strikes >= 3) {
+                        h->i8_strikes = 2;
+                        h->i8_cooldown = 4096;
+                    }
+                    no_i8 = true;
+                    h->stats.fallback_used |= 4;
                 }
-                h->i8_suppress = true;
-                h->stats.fallback_used |= 4;
-                via_i8 = false;
-                s.max_wave_cnt = 0;
-                s.max_qcount = 0;
             } else {
                 h->stats.fallback_used |= 1;
+                wc = std::max(wc, next_pow2((int64_t)s.max_wave_cnt));
+                qc = std::max(qc, next_pow2((int64_t)s.max_qcount));
             }
-            // (the counts of a timed-out batch mean nothing: its thresholds were never agreed on -- the buffers stay as they are)
-            const int wc = s.bar_timeout ? w.ws_wave_cap : std::max(w.ws_wave_cap, next_pow2((int64_t)s.max_wave_cnt));
-            const int qc = s.bar_timeout ? w.ws_qcap : std::max(w.ws_qcap, next_pow2((int64_t)s.max_qcount));
             CRH_TRY(ensure_workspace(h, w, wc, qc));
             const uint32_t *mask = nullptr;
             CRH_TRY(build_mask(h, w, p.filt, p.nfilt, &mask, st));
-            const int rc = enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st);
+            h->i8_suppress = no_i8;
+            const int rc = enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st, &path);
             h->i8_suppress = false;
             CRH_TRY(rc);
             CRH_HIP(hipStreamSynchronize(st));
@@ -624,6 +674,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         if (h->i8) h->qcap = 131072;   // ~21 k candidates per query and 10M Gaussian rows behind the int8 scan (37 k with 4096 sample tiles)
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
         if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
+        if (const char *er = getenv("CODERAG_HIP_ROWMAJOR")) h->want_xrow = er[0] != '0';
     }
     h->dtype = dtype;
     h->ncols = n_code_cols;
@@ -678,6 +729,7 @@ int crh_index_destroy(crh_index *h)
     }
     dev_free(h->x8);
     dev_free(h->srow);
+    dev_free(h->xrow);
     dev_free(h->i8stat);
     dev_free(h->status);
     dev_free(h->stage_q);
@@ -1098,7 +1150,7 @@ int crh_debug_fused_stamps(unsigned long long *out)
 int crh_debug_select_stamps(unsigned long long *out)
 {
     CRH_HIP(hipDeviceSynchronize());
-    CRH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_select_stamps), sizeof(unsigned long long) * 64 * 8));
+    CRH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_select_stamps), sizeof(unsigned long long) * 64 * 16));
     return CRH_OK;
 }
 #endif
@@ -1115,7 +1167,7 @@ int crh_index_set_nomination(crh_index *h, int mode)
 int crh_index_get_nomination(crh_index *h, int *mode_out)
 {
     if (!h || !mode_out) return fail(CRH_E_INVALID, "NULL argument");
-    const bool one_launch = h->fused_scan && h->fused_cooldown == 0 && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
+    const bool one_launch = h->fused_scan && !h->fused_resting() && h->nominate_max >= CRH_NOMINATE_BF16 && h->seed_tiles == 4096 && h->ksteps != 64;
     *mode_out = i8_use(h, 1, 100) ? CRH_NOMINATE_INT8 : (one_launch ? CRH_NOMINATE_BF16 : CRH_NOMINATE_BF16_3);
     return CRH_OK;
 }
@@ -1143,11 +1195,13 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     DeviceGuard g(h->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    // force_fallback (testing): 1 = start from absurdly small candidate buffers so the regrow-and-rerun path runs;
+    // force_fallback (testing): 1 = start from absurdly small candidate buffers so the regrow-and-rerun path runs (behind the int8
+    // scan: its one regrowth); 3 = the same, and the int8 scan may NOT regrow (its batches go to the bf16 scan: the strike path);
     // 2 = the one-launch scan's first grid-wide wait expects an arrival too many, so its time-out path runs
-    int wc = h->force_fallback == 1 ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
-    int qc = h->force_fallback == 1 ? 8 : std::max(h->qcap, h->ws.ws_qcap);
-    if (h->force_fallback != 1 && i8_use(h, 1, k)) {
+    const bool tiny = h->force_fallback == 1 || h->force_fallback == 3;
+    int wc = tiny ? 4 : std::max(h->wave_cap, h->ws.ws_wave_cap);
+    int qc = tiny ? 8 : std::max(h->qcap, h->ws.ws_qcap);
+    if (!tiny && i8_use(h, 1, k)) {
         // the int8 intervals nominate a fixed FRACTION of the rows (the thresholds come from a fixed number of sample tiles):
         // ~21 k per query and ~660 per wave of the int8 scan at 10M rows.  The defaults hold that twice over up to 10M rows; beyond,
         // the buffers grow with the index (the int8 scan cannot regrow them after the fact: an overflow sends the batch to bf16)
@@ -1207,8 +1261,7 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
         const uint32_t *mask = nullptr;
         // (the filter mask lives in the workspace: stream order puts its rebuild behind the previous batch's scan)
         CRH_TRY(build_mask(h, w, filters, n_filters, &mask, st));
-        CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st));
-        p.used_i8 = h->count > 0 && i8_use(h, b, k);   // (as enqueue_batch just decided)
+        CRH_TRY(enqueue_batch(h, w, p.q_dev, b, k, mask, row_base, p.out_s, p.out_r, p.slot, st, &p.path));
         h->pending.push_back(p);
     }
     if (!out_on_device || !queries_on_device) {

@@ -1003,11 +1003,12 @@ __device__ void wg_bitonic_desc(unsigned long long *keys, int P)
 // One of the two grid-wide waits of k_scan_fused: every storing wave drains its stores, the workgroup meets, ONE lane publishes
 // (agent-scope release, then the arrival) and polls the counter with relaxed loads until `expected` arrivals are in, acquires
 // (agent scope: this CU's L1 is invalidated) and the workgroup meets again -- the placement-independent protocol of the CDNA
-// guide (Guideline 16, counter form).  The spin is bounded in TIME (0.5 s): a workgroup that does not become resident (another
-// stream's kernel holding its CU) ends the wait with status->bar_timeout set; the host then voids the batch, puts the index
-// back on the three-launch form and runs the batch again (finish_pending).
-constexpr unsigned long long kGridWaitTicks = 50000000ull;
-__device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int expected, bool arrive, SearchStatus *status)
+// guide (Guideline 16, counter form).  The spin is bounded in TIME by the job: `ticks` (100 MHz) is what the host allows this
+// launch -- eight times what its pass should take, at least 2 ms (wait_ticks_for in crh_index.hip; round 3 allowed a flat 0.5 s,
+// 400 passes).  A workgroup that does not become resident in that time (another stream's kernels holding its CU) ends the wait
+// with status->bar_timeout set; the host then voids the batch, runs it again in the three-launch form, which needs no
+// co-residency, and keeps the index on that form for a while (finish_pending).
+__device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int expected, bool arrive, SearchStatus *status, unsigned int ticks)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1021,10 +1022,12 @@ __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int ex
         unsigned int spins = 0u;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > kGridWaitTicks) {
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > (unsigned long long)ticks) {
                 __hip_atomic_store(&status->bar_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+            // (somebody else's wait has given up: the batch is void, nobody needs to sit out the rest of the time)
+            if ((spins & 255u) == 128u && __hip_atomic_load(&status->bar_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1047,25 +1050,32 @@ __device__ __forceinline__ void grid_wait(unsigned int *counter, unsigned int ex
 // Phase clocks of a MEASUREMENT build (-DCRH_FUSED_STAMPS, tools/fused_stamps.py); in the product CRH_STAMP is nothing.
 #ifdef CRH_FUSED_STAMPS
 __device__ unsigned long long g_fused_stamps[256 * 8 + 256 * 16];
-__device__ unsigned long long g_select_stamps[64 * 8];
+__device__ unsigned long long g_select_stamps[64 * 16];   // per query: stamps 0..7, then survivors of a part, candidates, survivors of the query, rows given the canonical chain
 #define CRH_SEL_STAMP(n)                                                                          \
     do {                                                                                          \
-        if (threadIdx.x == 0 && blockIdx.x < 64) g_select_stamps[blockIdx.x * 8 + (n)] = wall_clock64(); \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_select_stamps[blockIdx.x * 16 + (n)] = wall_clock64(); \
     } while (0)
 #define CRH_STAMP(n)                                                                                      \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 256) g_fused_stamps[blockIdx.x * 8 + (n)] = wall_clock64();  \
     } while (0)
+// (sub-stamps of k_scan_i8's threshold phase, workgroups 0..63: they go to the per-wave slots 8..15 that its eight waves leave unused)
+#define CRH_TAU_STAMP(n)                                                                                                    \
+    do {                                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_fused_stamps[256 * 8 + blockIdx.x * 16 + (n)] = wall_clock64();          \
+    } while (0)
 #else
 #define CRH_STAMP(n) ((void)0)
 #define CRH_SEL_STAMP(n) ((void)0)
+#define CRH_TAU_STAMP(n) ((void)0)
 #endif
 
 template <int KSTEPS, int WAVES, int RING, int QB = 2>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     const u32x4 *__restrict__ xt, const u32x4 *__restrict__ qfrag, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
     float *__restrict__ gmax, float *__restrict__ tau_g, int k, float margin, int nq, u32x4 *__restrict__ wave_lists, int wave_cap,
-    unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status, int wait_extra)
+    unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, int qcap, SearchStatus *__restrict__ status, int wait_extra,
+    unsigned int wait_ticks)
 {
     // (wait_extra: 0; a test passes 1 -- wait A then expects an arrival that never comes, which exercises the time-out path)
     static_assert(KSTEPS % RING == 0, "ring must divide the k-steps of a tile");
@@ -1153,7 +1163,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
         for (int d = 0; d < RING; ++d) nt_load(ring[d], xp + piece_off(d));
     }
     CRH_STAMP(2);
-    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status);
+    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status, wait_ticks);
     CRH_STAMP(3);
 
     // ---- 2. thresholds: workgroup q (and q + gridDim.x, ...) owns query q
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_fused(
     }
     const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
     CRH_STAMP(4);
-    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status);
+    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status, wait_ticks);
     CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
     __syncthreads();
@@ -1342,6 +1352,36 @@ __device__ __forceinline__ float canonical_dot_tiled(const u32x4 *__restrict__ x
     return acc;
 }
 
+// The same sum from the row-major side copy of the bf16 rows (crh_i8.hpp, ROW-MAJOR ROWS): the same values in the same order,
+// so the same bits; a row is 12 full HBM lines instead of 48 quarter-used ones.
+template <int DEPTH = 8>   // 16-byte chunks in flight (nchunks % DEPTH == 0): the chain is a chain of memory round trips, nchunks / DEPTH deep
+__device__ __forceinline__ float canonical_dot_rows(const u32x4 *__restrict__ xrow, int dim, uint32_t row, const float *qv)
+{
+    const u32x4 *xr = xrow + (size_t)row * (size_t)(dim >> 3);
+    const int nchunks = dim >> 3;                      // chunk c = elements [8c, 8c + 8)
+    float acc = 0.0f;
+    u32x4 pk[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) pk[j] = xr[j];
+    for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
+        const bool more = c0 + DEPTH < nchunks;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const float *qq = qv + (c0 + j) * 8;
+            const uint32_t w[4] = {pk[j].x, pk[j].y, pk[j].z, pk[j].w};
+            if (more) pk[j] = xr[c0 + DEPTH + j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p0 = qq[2 * e] * bf16_bits_f32(w[e] & 0xffffu);
+                acc = acc + p0;
+                float p1 = qq[2 * e + 1] * bf16_bits_f32(w[e] >> 16);
+                acc = acc + p1;
+            }
+        }
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf32, int dim, uint32_t row, const float *qv)
 {
     const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
@@ -1365,6 +1405,64 @@ __device__ __forceinline__ float canonical_dot_f32(const float *__restrict__ xf3
         }
     }
     return acc;
+}
+
+// One lane's share of a row's dot with the query in LDS when EIGHT lanes split the row (lane `sub` takes every eighth 16-byte
+// chunk, so all of a row's bytes are requested at once); the caller adds the eight shares (three shfl_xor).  ANY summation
+// order: the result is within 2 * dim * 2^-24 * |q| |x| of the canonical score (both are f32 sums of the same dim products) --
+// it nominates or bounds, it never becomes a returned score.  xf32 != nullptr: the row comes from the f32 master.
+template <int DEPTH = 12>   // 16-byte loads a lane requests before it consumes the first (k_scan_i8's threshold phase has registers for 6)
+__device__ __forceinline__ float partial_dot8(const u32x4 *__restrict__ xt, const float *__restrict__ xf32, const u32x4 *__restrict__ xrow, int dim,
+                                              int ksteps, uint32_t row, const float *qv, int sub)
+{
+    float acc = 0.f;
+    if (xrow != nullptr) {                              // row-major bf16 rows (crh_i8.hpp, ROW-MAJOR ROWS): chunk c is 16 bytes at 16 c
+        const u32x4 *xr = xrow + (size_t)row * (size_t)(dim >> 3);
+#pragma unroll DEPTH
+        for (int c = sub; c < (dim >> 3); c += 8) {
+            const u32x4 pk = xr[c];
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+            const float *qq = qv + 8 * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = fmaf(qq[2 * j], bf16_bits_f32(w[j] & 0xffffu), acc);
+                acc = fmaf(qq[2 * j + 1], bf16_bits_f32(w[j] >> 16), acc);
+            }
+        }
+    } else if (xf32 != nullptr) {
+        const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
+#pragma unroll DEPTH
+        for (int c = sub; c < (dim >> 2); c += 8) {
+            const float4 x = xr[c];
+            const float *qq = qv + 4 * c;
+            acc = fmaf(qq[0], x.x, acc);
+            acc = fmaf(qq[1], x.y, acc);
+            acc = fmaf(qq[2], x.z, acc);
+            acc = fmaf(qq[3], x.w, acc);
+        }
+    } else {
+        const u32x4 *tp = xt + (size_t)(row >> 5) * ksteps * 64;
+        const int rin = (int)(row & 31u);
+#pragma unroll DEPTH
+        for (int c = sub; c < (dim >> 3); c += 8) {       // chunk c = elements [8c, 8c + 8) of the row
+            const u32x4 pk = tp[piece_off(c >> 1) + piece_slot(c & 1, rin)];
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+            const float *qq = qv + 8 * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = fmaf(qq[2 * j], bf16_bits_f32(w[j] & 0xffffu), acc);
+                acc = fmaf(qq[2 * j + 1], bf16_bits_f32(w[j] >> 16), acc);
+            }
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float sum8(float acc)
+{
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    return (acc == acc) ? acc : -INFINITY;   // (a stored row holding a NaN bounds nothing)
 }
 
 // Step 4 of k_select: exact top-k of Ms unique keys (descending score, ascending row), written with row_base added.  The keys
@@ -1445,7 +1543,8 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
                                                   const float *__restrict__ qn, const u32x4 *__restrict__ xt,
                                                   const float *__restrict__ xf32, int dim, int ksteps, int k,
                                                   float margin, int64_t row_base, float *__restrict__ out_scores,
-                                                  int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
+                                                  int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status,
+                                                  const u32x4 *__restrict__ xrow = nullptr)
 {
     constexpr int NT = 1024;
     constexpr unsigned int LCAP = 2048;   // survivors kept in LDS (the normal case: ~k + a few)
@@ -1534,11 +1633,129 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     const unsigned int Ms = scount;
     if (tid == 0 && blockIdx.x < 64) {
 #ifdef CRH_FUSED_STAMPS
-        g_select_stamps[blockIdx.x * 8 + 6] = Ms;
-        g_select_stamps[blockIdx.x * 8 + 7] = M;
+        g_select_stamps[blockIdx.x * 16 + 8] = Ms;
+        g_select_stamps[blockIdx.x * 16 + 9] = M;
 #endif
     }
     const bool in_lds = Ms <= LCAP;
+    if constexpr (I8) {
+        // Behind the int8 scan the survivors of a query are many (its intervals are wide) and the ordered 768-term chain of
+        // the canonical score is a chain of memory round trips per row.  So the survivors are first scored in ANY order, eight
+        // lanes per row with every byte of the row requested at once (partial_dot8: within `margin` / 2 of the canonical
+        // score); the canonical chain then runs only for the rows whose fast score lies within `margin` of the k-th largest
+        // fast score -- k + a few rows per query -- and decides every returned id and score as before.  (The true top-k pass:
+        // at most k - 1 rows score canonically above the true k-th score s*, so the k-th largest fast score is <= s* + margin / 2,
+        // and a row of the true top-k has fast >= s* - margin / 2.)
+        const int sub = tid & 7;
+        for (unsigned int p0 = 0; p0 < Ms; p0 += NT / 8) {
+            const unsigned int p = p0 + (unsigned int)(tid >> 3);
+            float acc = 0.f;
+            uint32_t row = 0u;
+            if (p < Ms) {
+                row = (uint32_t)(in_lds ? lkeys[p] : sk[p]);
+                acc = partial_dot8(xt, F32 ? xf32 : nullptr, F32 ? nullptr : xrow, dim, ksteps, row, qv, sub);
+            }
+            acc = sum8(acc);
+            if (p < Ms && sub == 0) {
+                const unsigned long long key = ((unsigned long long)ord_f32(acc) << 32) | (unsigned long long)(~row);
+                if (in_lds)
+                    lkeys[p] = key;
+                else
+                    sk[p] = key;
+            }
+        }
+        __syncthreads();
+        CRH_SEL_STAMP(3);
+        const unsigned long long *src = in_lds ? lkeys : sk;   // the fast keys the rest of this workgroup works from
+        unsigned long long *gsrc = sk;                          // ... and where they live when they are not in LDS
+        unsigned int Mt = Ms;
+        if (split) {
+            // publish this part's keys; the workgroup that arrives last takes all of them
+            if (tid == 0) bcast[0] = atomicAdd(&status->qsurv[q], Ms);
+            __syncthreads();
+            unsigned long long *fq = fin + (size_t)q * qcap;
+            const unsigned int gbase = bcast[0];
+            for (unsigned int p = tid; p < Ms; p += NT) fq[gbase + p] = src[p];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int arrived = __hip_atomic_fetch_add(&status->qdone[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned int total = 0u;
+                if (arrived == parts - 1u) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    total = __hip_atomic_load(&status->qsurv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bcast[0] = arrived == parts - 1u ? 1u : 0u;
+                bcast[1] = total;
+            }
+            __syncthreads();
+            if (bcast[0] == 0u) return;
+            Mt = bcast[1];
+            __syncthreads();
+            gsrc = fq;
+            if (Mt <= LCAP) {
+                for (unsigned int p = tid; p < Mt; p += NT) lkeys[p] = fq[p];
+                __syncthreads();
+                src = lkeys;
+            } else {
+                src = fq;
+            }
+        }
+        // the k-th largest fast score and the cut below it
+        const unsigned int k3 = (unsigned int)k < Mt ? (unsigned int)k : Mt;
+        const uint32_t fkey = wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return (uint32_t)(src[i] >> 32); }, Mt, k3, 0u, fast, hist, bcast);
+        const float fk = unord_f32(fkey);
+        const uint32_t cut = fk > -INFINITY ? ord_f32(fk - margin) : 0u;
+        constexpr unsigned int CCAP = SCAP / 2;                       // rows kept for the canonical chain: the candidate scores' LDS is free now
+        unsigned long long *ckeys = reinterpret_cast<unsigned long long *>(lscore);
+        __syncthreads();
+        if (tid == 0) scount = 0u;
+        __syncthreads();
+        for (unsigned int p = tid; p < Mt; p += NT) {
+            const unsigned long long key = src[p];
+            if ((uint32_t)(key >> 32) >= cut) {
+                const unsigned int o = atomicAdd(&scount, 1u);
+                if (o < CCAP) ckeys[o] = (unsigned long long)(uint32_t)(~(uint32_t)key);
+            }
+        }
+        __syncthreads();
+        const unsigned int Mc = scount;
+        CRH_SEL_STAMP(4);
+#ifdef CRH_FUSED_STAMPS
+        if (tid == 0 && blockIdx.x < 64) {
+            g_select_stamps[blockIdx.x * 16 + 10] = Mt;
+            g_select_stamps[blockIdx.x * 16 + 11] = Mc;
+        }
+#endif
+        if (Mc <= CCAP) {
+            for (unsigned int p = tid; p < Mc; p += NT) {
+                const uint32_t row = (uint32_t)ckeys[p];
+                const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : (xrow != nullptr ? canonical_dot_rows<8>(xrow, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv));
+                ckeys[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+            }
+            __syncthreads();
+            CRH_SEL_STAMP(5);
+            if (Mc > LCAP) {   // (thousands of rows within the margin of the k-th score: the general selection works from global memory)
+                for (unsigned int p = tid; p < Mc; p += NT) gsrc[p] = ckeys[p];
+                __syncthreads();
+            }
+            select_tail<NT>(gsrc, Mc, Mc <= LCAP, ckeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
+        } else {
+            // masses of (nearly) equal scores: every survivor gets the canonical chain, in place in global memory (Mt > CCAP > LCAP)
+            for (unsigned int p = tid; p < Mt; p += NT) {
+                const uint32_t row = ~(uint32_t)gsrc[p];
+                const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : (xrow != nullptr ? canonical_dot_rows<8>(xrow, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv));
+                gsrc[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
+            }
+            __syncthreads();
+            CRH_SEL_STAMP(5);
+            select_tail<NT>(gsrc, Mt, false, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
+        }
+        CRH_SEL_STAMP(6);
+        return;
+    }
     // Canonical re-score: one thread per survivor walks its row (96 pieces of 16 bytes, fetched 16 at a time, consumed in index
     // order).  Splitting a row over 2 / 4 / 8 lanes (all lanes fetch at once, the running sum handed from lane to lane in index
     // order, products formed ahead of the ordered additions) returns the same bits with a quarter of the memory round trips --
@@ -1555,40 +1772,6 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     }
     __syncthreads();
     CRH_SEL_STAMP(3);
-    if (split) {
-        // publish this part's keys; the workgroup that arrives last takes all of them
-        if (tid == 0) bcast[0] = atomicAdd(&status->qsurv[q], Ms);
-        __syncthreads();
-        unsigned long long *fq = fin + (size_t)q * qcap;
-        const unsigned int gbase = bcast[0];
-        for (unsigned int p = tid; p < Ms; p += NT) fq[gbase + p] = in_lds ? lkeys[p] : sk[p];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int arrived = __hip_atomic_fetch_add(&status->qdone[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned int total = 0u;
-            if (arrived == parts - 1u) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                total = __hip_atomic_load(&status->qsurv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            bcast[0] = arrived == parts - 1u ? 1u : 0u;
-            bcast[1] = total;
-        }
-        __syncthreads();
-        if (bcast[0] == 0u) return;
-        const unsigned int Mt = bcast[1];
-        __syncthreads();
-        const bool all_lds = Mt <= LCAP;
-        if (all_lds) {
-            for (unsigned int p = tid; p < Mt; p += NT) lkeys[p] = fq[p];
-            __syncthreads();
-        }
-        select_tail<NT>(fq, Mt, all_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
-        CRH_SEL_STAMP(4);
-        return;
-    }
     select_tail<NT>(sk, Ms, in_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
     CRH_SEL_STAMP(4);
 }

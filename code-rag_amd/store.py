@@ -354,6 +354,18 @@ class _Collection:
         self.shards.close()
 
 
+class RerankHits:
+    """Ids and payloads of the slots a ``search_rerank_batch`` output refers to, read while the slots still meant them."""
+
+    def __init__(self, by_slot: dict[int, tuple[Any, dict[str, Any]]], degrees: dict[str, int] | None):
+        self._by_slot = by_slot
+        self._degrees = degrees
+
+    def hit(self, slot: int, score: float) -> dict[str, Any]:
+        pid, payload = self._by_slot[int(slot)]
+        return {"id": pid, "score": score, "payload": payload}
+
+
 def ffi_index_tensor(vecs, keep):
     import torch
     return torch.as_tensor(keep, device=vecs.device, dtype=torch.int64)
@@ -636,6 +648,16 @@ class HipVectorStore:
         scores, slots = col.search(queries, limit, dfilt)
         return col, scores, slots
 
+    def _search_hits_sync(self, collection: str, queries: np.ndarray, limits, filters: dict[str, Any] | None) -> list[list[dict[str, Any]]]:
+        """One pass + the hit dictionaries of every query, built HERE -- inside the worker job, under the store's lock.  Slots
+        are positions in the host tables and a compaction renumbers them (the store compacts by itself after deletes and
+        replacing upserts): a slot handed back to the event loop could name another point, or none, by the time its payload is
+        read.  ``limits``: one int for all queries, or one per query (coalesced callers keep their own prefix)."""
+        per = [int(limits)] * queries.shape[0] if isinstance(limits, (int, np.integer)) else [int(v) for v in limits]
+        col, scores, slots = self._search_sync(collection, queries, max(per, default=0), filters)
+        return [[col.hit(int(r), float(s)) for s, r in zip(srow[:max(lim, 0)], rrow[:max(lim, 0)]) if r >= 0]
+                for lim, srow, rrow in zip(per, scores, slots)]
+
     async def search(self, collection: str, query_vector: list[float] | None, limit: int = 10,
                      filters: dict[str, Any] | None = None) -> list[dict[str, Any]]:
         """client.py:132-157: descending cosine, ``[{"id", "score", "payload"}]``.  ``query_vector=None`` is the
@@ -655,8 +677,7 @@ class HipVectorStore:
             else:
                 q = np.asarray(query_vector, dtype=np.float32).reshape(1, -1)
                 self.search_passes += 1
-                col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
-                results = [col.hit(int(r), float(s)) for s, r in zip(scores[0], rows[0]) if r >= 0]
+                results = (await self._run(self._search_hits_sync, collection, q, limit, filters))[0]
             logger.debug(f"Found {len(results)} results in {collection}")
             return results
         except Exception as e:
@@ -687,12 +708,11 @@ class HipVectorStore:
                 part = batch[start:start + 256]
                 try:
                     q = np.stack([b[0] for b in part])
-                    kmax = max(b[1] for b in part)
                     self.search_passes += (len(part) + 63) // 64
-                    col, scores, rows = await self._run(self._search_sync, name, q, kmax, filters)
-                    for (_, lim, fut), srow, rrow in zip(part, scores, rows):
+                    per_query = await self._run(self._search_hits_sync, name, q, [b[1] for b in part], filters)
+                    for (_, _, fut), hits in zip(part, per_query):
                         if not fut.done():
-                            fut.set_result([col.hit(int(r), float(s)) for s, r in zip(srow[:max(lim, 0)], rrow[:max(lim, 0)]) if r >= 0])
+                            fut.set_result(hits)
                 except Exception as e:  # noqa: BLE001 -- every caller of the pass sees the failure (wrapped by search())
                     for _, _, fut in part:
                         if not fut.done():
@@ -704,8 +724,7 @@ class HipVectorStore:
         serves up to 64 queries."""
         try:
             q = np.asarray(query_vectors, dtype=np.float32)
-            col, scores, rows = await self._run(self._search_sync, collection, q, limit, filters)
-            return [[col.hit(int(r), float(s)) for s, r in zip(srow, rrow) if r >= 0] for srow, rrow in zip(scores, rows)]
+            return await self._run(self._search_hits_sync, collection, q, limit, filters)
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)
 
@@ -717,9 +736,11 @@ class HipVectorStore:
     async def search_rerank_batch(self, collection: str, query_vectors, plans, reranker, limit: int = 20,
                                   filters: dict[str, Any] | None = None):
         """One corpus scan for all queries, then the hybrid re-rank of every candidate list on the device
-        (``ranking.device.DeviceReranker``): returns ``(collection, output, slots, scores)`` -- the :class:`RerankOutput` and the
-        host copies of the [nq, limit] candidate slots (``collection.hit(slot, score)``) / scores it indexes.  Payloads are read only for the survivors (see
-        ``engine_helpers.search_and_rank_batch_device``)."""
+        (``ranking.device.DeviceReranker``): returns ``(hits, output, slots, scores)`` -- the :class:`RerankOutput`, the host
+        copies of the [nq, limit] candidate slots / scores it indexes, and ``hits``: a :class:`RerankHits` whose
+        ``hit(slot, score)`` answers for every slot the output refers to (the survivors of each query; the whole list of a query
+        the device declined).  Their ids and payloads are read inside this job, under the store's lock: a compaction that runs
+        after it renumbers the slots (see ``_search_hits_sync``).  Payloads are still read only for the survivors."""
         import torch
         try:
             def work():
@@ -736,7 +757,12 @@ class HipVectorStore:
                 out = reranker.rank(s, r, col.gather_side(r), plans)
                 rows = r.cpu().numpy()
                 slots = col.slots_of(np.where(rows >= 0, rows // SHARD_STRIDE, 0), np.where(rows >= 0, rows % SHARD_STRIDE, -1))
-                return col, out, slots, s.cpu().numpy()
+                wanted = set()
+                for qi in range(nq):
+                    c = int(out.count[qi])
+                    pos = out.index[qi, :c] if c >= 0 else np.flatnonzero(slots[qi] >= 0)
+                    wanted.update(int(t) for t in slots[qi, pos] if t >= 0)
+                return RerankHits({t: (col.ids.get(t), col.payloads.get(t)) for t in wanted}, col._degrees), out, slots, s.cpu().numpy()
             return await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)

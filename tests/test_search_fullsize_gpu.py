@@ -104,3 +104,122 @@ def test_full_size_properties(gpu):
     assert np.array_equal(r3[0, : K - 1], r[20, 1:]) and r3[0, K - 1] not in r[20]
     for h in [full] + halves:
         h.close()
+
+
+def _kind_corpus(torch, kind, n, seed):
+    """Rows and queries of one corpus kind: bench.corpus_generator's, plus `shared-mean` -- one common direction with ISOTROPIC
+    noise (norm of the mean unit vector 0.86 like encoder output, but scores packed three times closer than its low-rank noise
+    packs them): the widest candidate sets the int8 intervals meet, where the one regrowth of its buffers has to happen."""
+    import bench
+    dev = torch.device("cuda:0")
+    if kind != "shared-mean":
+        return bench.corpus_generator(torch, dev, kind, seed, D)
+    r0 = np.random.default_rng(seed)
+    c = r0.standard_normal(D)
+    c /= np.linalg.norm(c)
+    c_d = torch.from_numpy(c.astype(np.float32)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    sig = (0.352 / D) ** 0.5
+    return (lambda m: c_d[None, :] + sig * torch.randn((m, D), generator=gen, device=dev),
+            lambda nq, qseed: (c[None, :] + sig * np.random.default_rng(qseed).standard_normal((nq, D))).astype(np.float32))
+
+
+@pytest.mark.parametrize("kind", ["clustered", "anisotropic", "shared-mean"])
+def test_corpus_kinds_at_2m_rows_against_the_oracle(gpu, kind):
+    """What the int8 intervals nominate depends on the data (SURVEY 8(d)'s clustered corpus; encoder-like rows with one shared
+    direction).  2M rows per kind, nominated from the int8 copy, ids and f32 score bits against the oracle; the candidate
+    buffers may grow once (bit 0 of fallback_used), the copy must not give way to the bf16 scan (bit 2) nor a wait time out."""
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd import ffi
+    from oracle import search as orc
+    n, nq = 2_000_000, 16
+    block_of, queries_of = _kind_corpus(torch, kind, n, 4242)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n)
+    parts = []
+    for r0 in range(0, n, BLOCK):
+        xb = block_of(BLOCK)
+        idx.append(xb)
+        parts.append(xb.cpu().numpy())
+        torch.cuda.synchronize()
+        del xb
+    x = np.concatenate(parts)
+    del parts
+    q = queries_of(nq, 99)
+    assert idx.nomination() == ffi.NOMINATE_INT8
+    s, r = idx.search(q, K)
+    st = idx.stats()
+    print(kind, st)
+    assert st["fallback_used"] & 6 == 0, st
+    es, er = orc.cosine_search(x, q, K, bf16=True)
+    assert np.array_equal(r, er), "ids differ from the oracle"
+    assert np.array_equal(s.view(np.uint32), es.view(np.uint32)), "score bits differ from the oracle"
+    s2, r2 = idx.search(q, K)                       # buffers are settled now: no regrowth the second time
+    assert idx.stats()["fallback_used"] == 0 and np.array_equal(r2, r) and np.array_equal(s2.view(np.uint32), s.view(np.uint32))
+    idx.close()
+
+
+def test_search_beside_an_encoder_forward_on_another_stream(gpu):
+    """The product runs the encoder (provider thread) and the store (its own thread) in one process
+    (/root/reference/src/lattice/providers/unixcoder_provider.py:260: the 1-worker executor beside the query path).  The
+    one-launch scans need their whole grid resident at two grid-wide waits; beside another stream's kernels a workgroup may not
+    be.  Here searches go out on stream A while a 65 k-token packed encoder forward runs on stream B: every result is bit-exact
+    (whether the waits held or a batch was recovered in the three-launch form), and a search costs at most 10 ms more than alone."""
+    import time
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd import encoder as drv, ffi
+    from oracle import search as orc
+    dev = torch.device("cuda:0")
+    n, nq, k = 1_000_000, 64, 100
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n)
+    parts = []
+    for r0 in range(0, n, BLOCK):
+        xb = torch.randn((BLOCK, D), generator=gen, device=dev)
+        idx.append(xb)
+        parts.append(xb.cpu().numpy())
+        del xb
+    x = np.concatenate(parts)
+    q = np.random.default_rng(78).standard_normal((nq, D)).astype(np.float32)
+    es, er = orc.cosine_search(x, q[:8], k, bf16=True)
+    qd = torch.from_numpy(q).to(dev)
+    cfg = drv.EncoderConfig()
+    model = drv.HipUniXcoder(drv.synthetic_weights(cfg, 23), cfg, drv.HashTokenizer(cfg.vocab_size), 0)
+    rng = np.random.default_rng(79)
+    lengths = np.full(256, 256, np.int64)                                       # 65 536 tokens: ~13 ms of back-to-back kernels
+    rows = [np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, int(L) - 4), [2]]).astype(np.int32) for L in lengths]
+    flat, off, Lmax = model.pack_rows(rows, list(range(len(rows))))
+    ids_d, off_d = torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev)
+    sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    out_s = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(8)]
+    out_r = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(8)]
+    with torch.cuda.stream(sB):
+        ref_emb = model.forward_packed(ids_d, off_d, Lmax).clone()             # warm-up + the embedding every later forward must repeat
+    torch.cuda.synchronize()
+
+    def one_search(i):
+        t0 = time.perf_counter()
+        idx.search(qd, k, out_scores=out_s[i], out_rows=out_r[i], stream=sA.cuda_stream)
+        idx.search_finish(sA.cuda_stream)
+        return (time.perf_counter() - t0) * 1e3
+    alone = [one_search(i) for i in range(8)][2:]
+    assert idx.stats()["fallback_used"] == 0 and idx.nomination() == ffi.NOMINATE_INT8
+    beside, fallbacks = [], 0
+    for rep in range(3):
+        with torch.cuda.stream(sB):
+            emb = model.forward_packed(ids_d, off_d, Lmax)                      # ~1000 launches queued on B; returns while they run
+        for i in range(8):
+            beside.append(one_search(i))
+            fallbacks |= idx.stats()["fallback_used"]
+            got_s, got_r = out_s[i][:8].cpu().numpy(), out_r[i][:8].cpu().numpy()
+            assert np.array_equal(got_r, er) and np.array_equal(got_s.view(np.uint32), es.view(np.uint32)), (rep, i)
+        sB.synchronize()
+        assert torch.equal(emb, ref_emb)                                        # the encoder is not disturbed either
+    print(f"search alone {np.median(alone):.3f} ms (max {max(alone):.3f}); beside the forward median {np.median(beside):.3f} ms, max {max(beside):.3f} ms; "
+          f"fallback bits seen {fallbacks}")
+    assert fallbacks & ~2 == 0                                                  # bit 1 (a wait timed out, batch recovered) may or may not appear
+    assert max(beside) <= max(alone) + 10.0
+    idx.close()

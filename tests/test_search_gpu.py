@@ -545,8 +545,10 @@ def test_fused_scan_equals_the_three_kernel_form_and_the_oracle(gpu, monkeypatch
 
 def test_fused_scan_that_times_out_is_run_again_in_the_three_kernel_form(gpu):
     """The one-launch scan needs every workgroup resident at its grid-wide waits.  When one is not (another stream's kernels on
-    its CU) the wait gives up after 0.5 s, the batch is void, and the host runs it again with the three-launch form and keeps the
-    index on it.  Provoked here through the tuning hook (wait A expects an arrival too many)."""
+    its CU) the wait gives up after a bound set by the job (eight pass times, at least 2 ms), the batch is void, and the host
+    runs it again with the three-launch form and keeps the index on it for a WINDOW OF TIME (0.2 s, doubling with every further
+    time-out).  Provoked here through the tuning hook (wait A expects an arrival too many)."""
+    import time
     ffi = _ffi()
     rng = np.random.default_rng(5)
     n = 30_000
@@ -556,13 +558,25 @@ def test_fused_scan_that_times_out_is_run_again_in_the_three_kernel_form(gpu):
     idx = ffi.Index(768, ffi.DTYPE_BF16, capacity_rows=n)
     idx.append(x)
     s, r = idx.search(q, 25)
-    assert idx.stats()["fallback_used"] == 0 and np.array_equal(r, er)
+    one_launch = idx.nomination()
+    assert idx.stats()["fallback_used"] == 0 and np.array_equal(r, er) and one_launch in (ffi.NOMINATE_BF16, ffi.NOMINATE_INT8)
     idx.set_tuning(force_fallback=2)
-    s, r = idx.search(q, 25)                                   # ~0.5 s: every workgroup sits out the bound
+    t0 = time.perf_counter()
+    s, r = idx.search(q, 25)                                   # every workgroup sits out the bound: milliseconds, not 0.5 s
+    assert time.perf_counter() - t0 < 0.1, "the wait's bound follows the job (2 ms here)"
     assert idx.stats()["fallback_used"] == 2
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
-    s, r = idx.search(q, 25)                                   # the index stays on the three-launch form for a while: no wait to time out
+    s, r = idx.search(q, 25)                                   # inside the window: three launches, no wait to time out
     assert idx.stats()["fallback_used"] == 0 and idx.nomination() == ffi.NOMINATE_BF16_3
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    time.sleep(0.25)                                           # the window is over: the one-launch form gets its next chance ...
+    assert idx.nomination() == one_launch
+    s, r = idx.search(q, 25)                                   # ... times out again (the hook is still on), and is recovered again
+    assert idx.stats()["fallback_used"] == 2 and np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+    idx.set_tuning(force_fallback=0)
+    time.sleep(0.45)                                           # (the second window was 0.4 s)
+    s, r = idx.search(q, 25)
+    assert idx.stats()["fallback_used"] == 0 and idx.nomination() == one_launch
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
     idx.close()
 
@@ -644,9 +658,12 @@ def test_int8_nomination_with_masses_of_identical_rows(gpu, bf16):
     idx.close()
 
 
-def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
-    """Intervals too wide for the buffers (here: buffers made tiny) -> the batch is run again on the bf16 scan (bit 2 of
-    fallback_used), which regrows ITS buffers (bit 0); after three such batches the copy is rested (4096 batches, then one more try)."""
+def test_int8_nomination_regrows_once_and_gives_way_when_that_is_refused(gpu):
+    """Intervals too wide for the candidate buffers (here: buffers made tiny).  Moderate counts (at most 2 % of the rows per
+    query): the buffers grow ONCE to the observed need and the batch runs again from the copy (bit 0 of fallback_used, bit 2
+    clear, the index stays on the copy).  Regrowth refused (tuning hook 3; in the field: counts beyond 2 % of the rows): the batch
+    is run again on the bf16 scan (bit 2), which regrows ITS buffers (bit 0); after three such batches the copy is rested (4096
+    batches, then one more try)."""
     ffi = _ffi()
     rng = np.random.default_rng(34)
     x = rng.standard_normal((40_000, D), dtype=np.float32)
@@ -656,6 +673,11 @@ def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
     _exact(idx, x, q, 20, True)
     assert idx.stats()["fallback_used"] == 0
     idx.set_tuning(force_fallback=1)
+    for _ in range(2):
+        _exact(idx, x, q, 20, True)
+        assert idx.stats()["fallback_used"] == 1, idx.stats()
+        assert idx.nomination() == ffi.NOMINATE_INT8
+    idx.set_tuning(force_fallback=3)
     for _ in range(3):
         _exact(idx, x, q, 20, True)
         assert idx.stats()["fallback_used"] & 4
@@ -663,6 +685,41 @@ def test_int8_nomination_gives_way_when_its_candidate_buffers_overflow(gpu):
     _exact(idx, x, q, 20, True)
     assert idx.stats()["fallback_used"] == 0          # three strikes: this index scans its bf16 rows for a while
     assert idx.nomination() == ffi.NOMINATE_BF16
+    idx.close()
+
+
+@pytest.mark.parametrize("dim", [768, 1536])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_saturated_rows_and_queries(gpu, dim, bf16):
+    """Rows and queries whose every element sits at +-max: the int8 images are all +-127 and the integer dots reach
+    127 * 127 * D -- 24.8M at D = 1536, beyond what f32 holds exactly, the case the rounding allowance of the intervals has to
+    cover (crh_i8.hpp, kDotRound; round 3 allowed 128 at every width).  Sign vectors close to a query's sign pattern (a few
+    flips), exact copies, their negatives, rows that are saturated except for a few zeros, all among ordinary rows."""
+    ffi = _ffi()
+    rng = np.random.default_rng(37 + dim)
+    n, nq = 24_000, 32
+    signs = rng.choice([-1.0, 1.0], (nq, dim)).astype(np.float32)
+    q = signs * np.float32(0.37)                                  # saturated queries: every |element| equal
+    x = rng.standard_normal((n, dim), dtype=np.float32)
+    sat = rng.choice(n, 12_000, replace=False)
+    pick = rng.integers(0, nq, len(sat))
+    rows = signs[pick].copy()
+    flips = rng.integers(0, 40, len(sat))                         # 0..39 flipped signs: scores packed closely under 1.0
+    for i, f in enumerate(flips):
+        if f:
+            rows[i, rng.choice(dim, f, replace=False)] *= -1.0
+    rows[::7] *= -1.0                                             # the most negative dots as well
+    zero_some = rng.choice(len(sat), 2000, replace=False)
+    for i in zero_some:
+        rows[i, rng.choice(dim, 5, replace=False)] = 0.0
+    x[sat] = rows * rng.choice([1.0, 3.0, 1e-3], (len(sat), 1)).astype(np.float32)   # (normalised on insert: the scale is irrelevant, the pattern is not)
+    q[-4:] = rng.standard_normal((4, dim), dtype=np.float32)      # ordinary queries against saturated rows
+    idx = ffi.Index(dim, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n)
+    idx.append(x)
+    assert idx.nomination() == ffi.NOMINATE_INT8
+    for k in (1, 10, 100):
+        _exact(idx, x, q, k, bf16)
+    assert idx.stats()["fallback_used"] & 6 == 0, idx.stats()
     idx.close()
 
 

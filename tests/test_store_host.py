@@ -137,3 +137,58 @@ def test_raw_client_matchtext_resolves_through_the_code_dictionaries(fake):
             await s.client.delete("code_chunks", points_selector=M(filter=M(must=[])))          # no condition: every point
             assert (await s.get_collection_info("code_chunks")).points_count == 0
     asyncio.run(go())
+
+
+def test_hits_are_resolved_inside_the_job_so_a_compaction_cannot_renumber_them(fake):
+    """Round-3 advisor finding: searches returned raw SLOTS to the event loop and read ids / payloads there, while the next
+    queued job (the reference indexer's delete-and-reupsert of a file, embeddings/indexer.py:61-64) could compact the tables and
+    renumber every slot.  Searches, a compaction-triggering delete and the device re-rank's hit view are interleaved here: every
+    hit must carry the id and payload of the row whose VECTOR was found."""
+    rng = np.random.default_rng(11)
+    n = 600
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    pay = [{"file_path": f"/p/f{i % 6}.py", "entity_type": "function", "entity_name": f"fn_{i}", "language": "python", "start_line": i,
+            "end_line": i + 1, "content": f"body {i}", "graph_node_id": None, "content_hash": "h", "project_name": "p"} for i in range(n)]
+
+    async def go():
+        async with store_mod.HipVectorStore(dim=768, initial_capacity=1024, compact_dead_fraction=0.1, compact_min_dead=8) as st:
+            await st.create_collections()
+            await st.upsert("code_chunks", [f"id{i}" for i in range(n)], vecs, pay)
+            keep = [i for i in range(n) if i % 6 not in (0, 1)]           # files f0 and f1 go away below: 1/3 of the rows, in front
+
+            async def searches():
+                out = []
+                for i in keep[:40]:
+                    out.append((i, await st.search("code_chunks", vecs[i].tolist(), limit=3)))
+                    await asyncio.sleep(0)
+                return out
+
+            async def deletes():
+                await asyncio.sleep(0)
+                await st.delete("code_chunks", {"file_path": "/p/f0.py"})
+                await st.delete("code_chunks", {"file_path": "/p/f1.py"})
+
+            found, _ = await asyncio.gather(searches(), deletes())
+            info = await st.get_collection_info("code_chunks")
+            assert info.config["compactions"] >= 1 and info.points_count == len(keep)
+            for i, hits in found:
+                assert hits[0]["id"] == f"id{i}" and hits[0]["payload"]["entity_name"] == f"fn_{i}", (i, hits[0])
+            # after the compaction: slots have moved, results have not
+            for i in keep[::37]:
+                top = (await st.search("code_chunks", vecs[i].tolist(), limit=1))[0]
+                assert top["id"] == f"id{i}" and top["payload"]["start_line"] == i
+            batch = await st.search_batch("code_chunks", vecs[keep[:5]], limit=2)
+            assert [b[0]["id"] for b in batch] == [f"id{i}" for i in keep[:5]]
+    asyncio.run(go())
+
+
+def test_search_hits_sync_builds_hits_under_the_lock(fake):
+    """The worker job itself returns hit dictionaries (never slots): what makes the test above hold by construction."""
+    async def go():
+        async with store_mod.HipVectorStore(dim=768, initial_capacity=64) as st:
+            await st.create_collections()
+            v = np.eye(768, dtype=np.float32)[:4]
+            await st.upsert("code_chunks", ["a", "b", "c", "d"], v, [{"file_path": f"{c}.py"} for c in "abcd"])
+            hits = await st._run(st._search_hits_sync, "code_chunks", v[:2], [1, 2], None)
+            assert [len(h) for h in hits] == [1, 2] and hits[0][0]["id"] == "a" and hits[1][0]["payload"] == {"file_path": "b.py"}
+    asyncio.run(go())

@@ -33,9 +33,9 @@ for it in range(12):
     if it >= 2:
         acc.append(buf[:2048].reshape(256, 8).astype(np.int64))
         wacc.append(buf[2048:].reshape(256, 16).astype(np.int64))
-        sb = np.zeros(64 * 8, np.uint64)
+        sb = np.zeros(64 * 16, np.uint64)
         assert L.crh_debug_select_stamps(sb.ctypes.data) == 0
-        sel.append(sb.reshape(64, 8).astype(np.int64))
+        sel.append(sb.reshape(64, 16).astype(np.int64))
 names = ["query image", "sample tile", "wait A", "threshold", "wait B", "main loop"]
 a = np.stack(acc)                                    # [runs, wg, stamp]
 t0 = a[:, :, 0].min(axis=1, keepdims=True)           # the first workgroup's entry
@@ -50,8 +50,15 @@ for i, n in enumerate(names):
 tauwg = d[:, :B, 3]; rest = d[:, B:, 3]
 print(f"threshold phase: workgroups 0..{B-1} (one query each) median {np.median(tauwg):.1f} us, the others {np.median(rest):.1f} us")
 w = (np.stack(wacc) - t0[:, :, None]) / 100.0            # [runs, wg, wave]: end of each wave's main loop
+wa = np.stack(wacc)
+if (wa[:, :B, 8:13] > 0).all():      # k_scan_i8: sub-stamps of the threshold phase of workgroups 0..63 (slots 8..12)
+    base = a[:, :B, 3]               # past wait A
+    tt = (wa[:, :B, 8:13] - base[:, :, None]) / 100.0
+    print("threshold phase of a query's workgroup, us after wait A -- keys in LDS / k-th largest key / rows selected / their scores / k-th largest score: "
+          + " ".join(f"{np.median(tt[:, :, i]):.1f}" for i in range(5)))
+    w = w[:, :, :8]
 print("end of the main loop per wave slot (us after kernel entry), median over workgroups and runs:")
-print("  " + " ".join(f"{np.median(w[:, :, i]):7.0f}" for i in range(16)))
+print("  " + " ".join(f"{np.median(w[:, :, i]):7.0f}" for i in range(w.shape[2])))
 print(f"  earliest wave {w.min(axis=(1, 2)).mean():.0f}, median {np.median(w):.0f}, last wave {w.max(axis=(1, 2)).mean():.0f}")
 e = (a[:, :, 6] - t0) / 100.0                        # [runs, wg]: wave 0 of each workgroup leaves the main loop
 print("end of the main loop by XCD (workgroup % 8): min / median / max, mean over runs")
@@ -63,9 +70,16 @@ print("  all workgroups, percentiles 0/5/25/50/75/95/100: " + " ".join(f"{v:.0f}
 if (a[:, :, 7] > 0).all():
     v = (a[:, :, 7] - a[:, :, 6]) / 100.0
     print(f"hand-over of the candidates after the main loop (us): median {np.median(v):.1f}, max {v.max(axis=1).mean():.1f}; kernel end {((a[:, :, 7] - t0) / 100.0).max(axis=1).mean():.0f}")
-sl = np.stack(sel)                                   # [runs, query, stamp]; 6 = survivors, 7 = candidates
-ph = np.diff(sl[:, :, :5], axis=2) / 100.0
-print("k_select per query workgroup (us): k-th largest / survivor sweep / canonical re-score / ranking -- median, max over queries; mean over runs")
-for i, n in enumerate(["k-th largest", "survivor sweep", "re-score", "ranking"]):
+sl = np.stack(sel)                                   # [runs, query, 16]: stamps 0..7; 8 survivors of a part, 9 candidates, 10 survivors of the query, 11 rows given the canonical chain
+i8 = (sl[:, :, 6] > 0).all()
+if i8:    # behind the int8 scan: 0 entry, 1 k-th largest lower end, 2 survivor sweep, 3 fast scores, 4 (last part) gathered + cut, 5 canonical chain, 6 ranked
+    names_s, last = ["k-th largest", "survivor sweep", "fast scores", "publish + cut", "canonical chain", "ranking"], 7
+else:     # bf16 scans: 0 entry, 1 k-th largest, 2 survivor sweep, 3 canonical re-score, 4 ranked
+    names_s, last = ["k-th largest", "survivor sweep", "re-score", "ranking"], 5
+ph = np.diff(sl[:, :, :last], axis=2) / 100.0
+print("k_select per query workgroup (us) -- median, max over queries; mean over runs (stamps 0..3 are those of the part that wrote last)")
+for i, n in enumerate(names_s):
     print(f"  {n:15s} {np.median(ph[:, :, i], axis=1).mean():8.1f} {ph[:, :, i].max(axis=1).mean():8.1f}")
-print(f"  candidates per query: median {np.median(sl[:, :, 7]):.0f}, max {sl[:, :, 7].max()};  survivors: median {np.median(sl[:, :, 6]):.0f}, max {sl[:, :, 6].max()}")
+print(f"  whole kernel per query: median {np.median((sl[:, :, last - 1] - sl[:, :, 0]) / 100.0):.1f} us")
+print(f"  candidates per query: median {np.median(sl[:, :, 9]):.0f}, max {sl[:, :, 9].max()};  survivors of a part: median {np.median(sl[:, :, 8]):.0f}, max {sl[:, :, 8].max()}"
+      + (f";  survivors of the query: median {np.median(sl[:, :, 10]):.0f}, max {sl[:, :, 10].max()};  canonical chains: median {np.median(sl[:, :, 11]):.0f}, max {sl[:, :, 11].max()}" if i8 else ""))
