@@ -134,14 +134,15 @@ __global__ __launch_bounds__(64) void k_requant_i8(const u32x4 *__restrict__ xt,
 }
 
 // ------------------------------------------------------------------ canonical queries -> 15-bit integer images
-// One wave per query slot (64 of them; slots >= nq hold zero queries).  qn: the canonical queries k_prep_queries wrote.
+// One wave per query slot (64 of them; slots >= nq hold zero queries).  src: the canonical query k_prep_queries has just worked out.
 // qfrag8: [QB][2 (H, L)][KS8][64] u32x4 MFMA operand pieces (lane l: query 32 b + (l & 31), elements 32p + 16 (l >> 5) .. + 15).
 // qpar:   [64][4] = s_q, |Q|_2, gn (bound of |g|_2), 0.
-__global__ __launch_bounds__(64) void k_prep_queries_i8(const float *__restrict__ qn, int dim, u32x4 *__restrict__ qfrag8,
-                                                        float *__restrict__ qpar)
+// Called by k_prep_queries<.., true> (crh_kernels.hpp) with the canonical query still in LDS: one launch prepares both images
+// (round 3 launched a second kernel that read the canonical queries back from global memory).
+__device__ __forceinline__ void prep_query_i8(const float *src /* the canonical query, LDS */, int dim, int qi, u32x4 *__restrict__ qfrag8,
+                                              float *__restrict__ qpar)
 {
-    const int qi = blockIdx.x, lane = threadIdx.x;
-    const float *src = qn + (size_t)qi * dim;
+    const int lane = threadIdx.x;
     const int ks8 = dim >> 5, qb = qi >> 5, c = qi & 31;
     float m = 0.f;
     for (int i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(src[i]));

@@ -425,19 +425,24 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
     const int width = wide ? nblk * 32 : h->batch_q;       // query slots prepared (slots >= nq are zero queries, tau = +inf)
     const int qstride = wide ? kWideQ : 64;                // row pitch of the seed maxima
 
-    if (h->dtype == CRH_DTYPE_BF16)
-        hipLaunchKernelGGL(k_prep_queries<true>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
-    else
-        hipLaunchKernelGGL(k_prep_queries<false>, dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt);
-    CRH_HIP(hipGetLastError());
-
     // <= batch_q queries, nominated from the int8 copy (crh_i8.hpp): half the bytes of the pass, same results
     if (i8_use(h, nq, k)) {
         CRH_TRY(i8_sync(h, st));
     }
-    if (i8_use(h, nq, k)) {   // (i8_sync may have given the copy up for lack of memory)
-        hipLaunchKernelGGL(k_prep_queries_i8, dim3(h->batch_q), dim3(64), 0, st, w.qn, h->dim, w.qfrag8, w.qpar);
-        CRH_HIP(hipGetLastError());
+    const bool via_i8 = i8_use(h, nq, k);   // (i8_sync may have given the copy up for lack of memory)
+    if (via_i8) {    // one launch prepares the bf16 image, the canonical queries and the integer images
+        if (h->dtype == CRH_DTYPE_BF16)
+            hipLaunchKernelGGL((k_prep_queries<true, true>), dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt, w.qfrag8, w.qpar);
+        else
+            hipLaunchKernelGGL((k_prep_queries<false, true>), dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt, w.qfrag8, w.qpar);
+    } else if (h->dtype == CRH_DTYPE_BF16) {
+        hipLaunchKernelGGL((k_prep_queries<true, false>), dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt, (u32x4 *)nullptr, (float *)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_prep_queries<false, false>), dim3(width), dim3(64), 0, st, q_dev, nq, h->dim, h->ksteps, w.qn, w.qfrag, stt, (u32x4 *)nullptr, (float *)nullptr);
+    }
+    CRH_HIP(hipGetLastError());
+
+    if (via_i8) {
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
         const int G8 = (int)std::min<int64_t>(h->seed_tiles == 4096 ? h->i8_sample : h->seed_tiles, ntiles);
         const int S8 = (int)std::max<int64_t>(1, ntiles / G8);
@@ -454,6 +459,14 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         else
             hipLaunchKernelGGL((k_select<false, true>), dim3(nq, kI8SelectParts), dim3(1024), 0, st, w.qlist, w.qlo, stt->qcount, qcap, w.skeys, w.skeys2, w.qn, h->xt,
                                h->xf32, h->dim, h->ksteps, k, 2.f * c_abs, row_base, out_s, out_r, stt, h->xrow);
+        CRH_HIP(hipGetLastError());
+        // the canonical chains of the few rows the fast scores leave, and the ranking (the kernel boundary is where a query's workgroups meet)
+        if (h->dtype == CRH_DTYPE_F32)
+            hipLaunchKernelGGL(k_select_final<true>, dim3(nq, kI8SelectParts), dim3(256), 0, st, w.skeys2, w.skeys, qcap, w.qn, h->xt, h->xf32, (const u32x4 *)nullptr,
+                               h->dim, h->ksteps, k, 2.f * c_abs, row_base, out_s, out_r, stt);
+        else
+            hipLaunchKernelGGL(k_select_final<false>, dim3(nq, kI8SelectParts), dim3(256), 0, st, w.skeys2, w.skeys, qcap, w.qn, h->xt, h->xf32, h->xrow,
+                               h->dim, h->ksteps, k, 2.f * c_abs, row_base, out_s, out_r, stt);
         CRH_HIP(hipGetLastError());
         h->stats.rows += h->count;
         h->stats.tiles += ntiles;

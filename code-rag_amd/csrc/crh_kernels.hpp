@@ -44,8 +44,10 @@ struct SearchStatus {
     unsigned int bar_timeout;    // set when one of those waits gave up (a workgroup never became resident): results are void
     unsigned int next_chunk;     // k_scan_i8: tile chunks handed out so far beyond each workgroup's first (zeroed with the slot)
     unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
-    unsigned int qsurv[kMaxQ];    // k_select split over several workgroups per query: survivors published so far ...
-    unsigned int qdone[kMaxQ];    // ... and workgroups that have published (the last one ranks)
+    unsigned int qsurv[kMaxQ];    // k_select behind the int8 scan, several workgroups per query: fast-scored survivors published so far
+    unsigned int qdone[kMaxQ];    // (unused since round 4: the kernel boundary before k_select_final is the meeting point)
+    unsigned int qsurv2[kMaxQ];   // k_select_final, several workgroups per query: canonical keys published so far ...
+    unsigned int qdone2[kMaxQ];   // ... and workgroups that have published (the last one ranks)
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -330,9 +332,12 @@ __global__ void k_compact_alive(uint32_t *__restrict__ alive, int64_t new_count,
 // qn:    [64][dim] f32 -- the canonical query the rescoring uses: cosine_preprocess(q), and for a
 //        bf16 store additionally rounded to bf16 (what the oracle scores with).
 // qfrag: [2][ksteps][64] u32x4 -- bf16 B-operand pieces for the scan.
-template <bool ROUND_BF16>
+__device__ __forceinline__ void prep_query_i8(const float *src, int dim, int qi, u32x4 *__restrict__ qfrag8, float *__restrict__ qpar);   // crh_i8.hpp
+
+template <bool ROUND_BF16, bool I8 = false>
 __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q, int nq, int dim, int ksteps,
-                                                     float *__restrict__ qn, u32x4 *__restrict__ qfrag, SearchStatus *__restrict__ status)
+                                                     float *__restrict__ qn, u32x4 *__restrict__ qfrag, SearchStatus *__restrict__ status,
+                                                     u32x4 *__restrict__ qfrag8 = nullptr, float *__restrict__ qpar = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float qs[2048];
     __shared__ float dv_s;
@@ -385,6 +390,14 @@ __global__ __launch_bounds__(64) void k_prep_queries(const float *__restrict__ q
         pk.z = hb[4] | (hb[5] << 16);
         pk.w = hb[6] | (hb[7] << 16);
         qfrag[((size_t)qb * ksteps + (c8 >> 1)) * 64 + ((c8 & 1) * 32 + c)] = pk;
+        if (I8) {   // (each thread rewrites the elements it alone has read: the canonical query replaces the raw one in LDS)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qs[c8 * 8 + j] = v[j];
+        }
+    }
+    if (I8) {       // the 15-bit integer images of the canonical query for the scan over the int8 copy (crh_i8.hpp)
+        __syncthreads();
+        prep_query_i8(qs, dim, qi, qfrag8, qpar);
     }
 }
 
@@ -1416,42 +1429,36 @@ __device__ __forceinline__ float partial_dot8(const u32x4 *__restrict__ xt, cons
                                               int ksteps, uint32_t row, const float *qv, int sub)
 {
     float acc = 0.f;
-    if (xrow != nullptr) {                              // row-major bf16 rows (crh_i8.hpp, ROW-MAJOR ROWS): chunk c is 16 bytes at 16 c
-        const u32x4 *xr = xrow + (size_t)row * (size_t)(dim >> 3);
-#pragma unroll DEPTH
-        for (int c = sub; c < (dim >> 3); c += 8) {
-            const u32x4 pk = xr[c];
-            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-            const float *qq = qv + 8 * c;
+    const int nch = xf32 != nullptr && xrow == nullptr ? (dim >> 2) : (dim >> 3);   // 16-byte chunks of the row: 4 f32 or 8 bf16 each
+    const u32x4 *rr = xrow != nullptr ? xrow + (size_t)row * (size_t)nch                                  // row-major bf16 rows (crh_i8.hpp, ROW-MAJOR ROWS)
+                      : xf32 != nullptr ? reinterpret_cast<const u32x4 *>(xf32 + (size_t)row * dim)       // the f32 master, row-major
+                                        : xt + (size_t)(row >> 5) * ksteps * 64;                          // the tiled bf16 image
+    const bool tiled = xrow == nullptr && xf32 == nullptr, f32 = xrow == nullptr && xf32 != nullptr;
+    const int rin = (int)(row & 31u);
+    for (int c0 = sub; c0 < nch; c0 += 8 * DEPTH) {
+        u32x4 pk[DEPTH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc = fmaf(qq[2 * j], bf16_bits_f32(w[j] & 0xffffu), acc);
-                acc = fmaf(qq[2 * j + 1], bf16_bits_f32(w[j] >> 16), acc);
-            }
+        for (int j = 0; j < DEPTH; ++j) {
+            const int c = c0 + 8 * j;
+            if (c < nch) pk[j] = tiled ? rr[piece_off(c >> 1) + piece_slot(c & 1, rin)] : rr[c];
         }
-    } else if (xf32 != nullptr) {
-        const float4 *xr = reinterpret_cast<const float4 *>(xf32 + (size_t)row * dim);
-#pragma unroll DEPTH
-        for (int c = sub; c < (dim >> 2); c += 8) {
-            const float4 x = xr[c];
-            const float *qq = qv + 4 * c;
-            acc = fmaf(qq[0], x.x, acc);
-            acc = fmaf(qq[1], x.y, acc);
-            acc = fmaf(qq[2], x.z, acc);
-            acc = fmaf(qq[3], x.w, acc);
-        }
-    } else {
-        const u32x4 *tp = xt + (size_t)(row >> 5) * ksteps * 64;
-        const int rin = (int)(row & 31u);
-#pragma unroll DEPTH
-        for (int c = sub; c < (dim >> 3); c += 8) {       // chunk c = elements [8c, 8c + 8) of the row
-            const u32x4 pk = tp[piece_off(c >> 1) + piece_slot(c & 1, rin)];
-            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-            const float *qq = qv + 8 * c;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc = fmaf(qq[2 * j], bf16_bits_f32(w[j] & 0xffffu), acc);
-                acc = fmaf(qq[2 * j + 1], bf16_bits_f32(w[j] >> 16), acc);
+        for (int j = 0; j < DEPTH; ++j) {
+            const int c = c0 + 8 * j;
+            if (c < nch) {
+                const uint32_t w[4] = {pk[j].x, pk[j].y, pk[j].z, pk[j].w};
+                if (f32) {
+                    const float *qq = qv + 4 * c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(qq[e], bits_f32(w[e]), acc);
+                } else {
+                    const float *qq = qv + 8 * c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc = fmaf(qq[2 * e], bf16_bits_f32(w[e] & 0xffffu), acc);
+                        acc = fmaf(qq[2 * e + 1], bf16_bits_f32(w[e] >> 16), acc);
+                    }
+                }
             }
         }
     }
@@ -1642,10 +1649,10 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
         // Behind the int8 scan the survivors of a query are many (its intervals are wide) and the ordered 768-term chain of
         // the canonical score is a chain of memory round trips per row.  So the survivors are first scored in ANY order, eight
         // lanes per row with every byte of the row requested at once (partial_dot8: within `margin` / 2 of the canonical
-        // score); the canonical chain then runs only for the rows whose fast score lies within `margin` of the k-th largest
-        // fast score -- k + a few rows per query -- and decides every returned id and score as before.  (The true top-k pass:
-        // at most k - 1 rows score canonically above the true k-th score s*, so the k-th largest fast score is <= s* + margin / 2,
-        // and a row of the true top-k has fast >= s* - margin / 2.)
+        // score); k_select_final then runs the canonical chain only for the rows whose fast score lies within `margin` of the
+        // k-th largest fast score -- k + a few rows per query -- and decides every returned id and score as before.  (The true
+        // top-k pass: at most k - 1 rows score canonically above the true k-th score s*, so the k-th largest fast score is
+        // <= s* + margin / 2, and a row of the true top-k has fast >= s* - margin / 2.)
         const int sub = tid & 7;
         for (unsigned int p0 = 0; p0 < Ms; p0 += NT / 8) {
             const unsigned int p = p0 + (unsigned int)(tid >> 3);
@@ -1666,94 +1673,12 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
         }
         __syncthreads();
         CRH_SEL_STAMP(3);
-        const unsigned long long *src = in_lds ? lkeys : sk;   // the fast keys the rest of this workgroup works from
-        unsigned long long *gsrc = sk;                          // ... and where they live when they are not in LDS
-        unsigned int Mt = Ms;
-        if (split) {
-            // publish this part's keys; the workgroup that arrives last takes all of them
-            if (tid == 0) bcast[0] = atomicAdd(&status->qsurv[q], Ms);
-            __syncthreads();
-            unsigned long long *fq = fin + (size_t)q * qcap;
-            const unsigned int gbase = bcast[0];
-            for (unsigned int p = tid; p < Ms; p += NT) fq[gbase + p] = src[p];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned int arrived = __hip_atomic_fetch_add(&status->qdone[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned int total = 0u;
-                if (arrived == parts - 1u) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    total = __hip_atomic_load(&status->qsurv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bcast[0] = arrived == parts - 1u ? 1u : 0u;
-                bcast[1] = total;
-            }
-            __syncthreads();
-            if (bcast[0] == 0u) return;
-            Mt = bcast[1];
-            __syncthreads();
-            gsrc = fq;
-            if (Mt <= LCAP) {
-                for (unsigned int p = tid; p < Mt; p += NT) lkeys[p] = fq[p];
-                __syncthreads();
-                src = lkeys;
-            } else {
-                src = fq;
-            }
-        }
-        // the k-th largest fast score and the cut below it
-        const unsigned int k3 = (unsigned int)k < Mt ? (unsigned int)k : Mt;
-        const uint32_t fkey = wg_kth_largest_fast<NT, 1024, 256>([&](unsigned int i) { return (uint32_t)(src[i] >> 32); }, Mt, k3, 0u, fast, hist, bcast);
-        const float fk = unord_f32(fkey);
-        const uint32_t cut = fk > -INFINITY ? ord_f32(fk - margin) : 0u;
-        constexpr unsigned int CCAP = SCAP / 2;                       // rows kept for the canonical chain: the candidate scores' LDS is free now
-        unsigned long long *ckeys = reinterpret_cast<unsigned long long *>(lscore);
+        // hand the fast keys over to k_select_final (the kernel boundary is the meeting point of a query's workgroups)
+        if (tid == 0) bcast[0] = Ms ? atomicAdd(&status->qsurv[q], Ms) : 0u;
         __syncthreads();
-        if (tid == 0) scount = 0u;
-        __syncthreads();
-        for (unsigned int p = tid; p < Mt; p += NT) {
-            const unsigned long long key = src[p];
-            if ((uint32_t)(key >> 32) >= cut) {
-                const unsigned int o = atomicAdd(&scount, 1u);
-                if (o < CCAP) ckeys[o] = (unsigned long long)(uint32_t)(~(uint32_t)key);
-            }
-        }
-        __syncthreads();
-        const unsigned int Mc = scount;
-        CRH_SEL_STAMP(4);
-#ifdef CRH_FUSED_STAMPS
-        if (tid == 0 && blockIdx.x < 64) {
-            g_select_stamps[blockIdx.x * 16 + 10] = Mt;
-            g_select_stamps[blockIdx.x * 16 + 11] = Mc;
-        }
-#endif
-        if (Mc <= CCAP) {
-            for (unsigned int p = tid; p < Mc; p += NT) {
-                const uint32_t row = (uint32_t)ckeys[p];
-                const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : (xrow != nullptr ? canonical_dot_rows<8>(xrow, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv));
-                ckeys[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
-            }
-            __syncthreads();
-            CRH_SEL_STAMP(5);
-            if (Mc > LCAP) {   // (thousands of rows within the margin of the k-th score: the general selection works from global memory)
-                for (unsigned int p = tid; p < Mc; p += NT) gsrc[p] = ckeys[p];
-                __syncthreads();
-            }
-            select_tail<NT>(gsrc, Mc, Mc <= LCAP, ckeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
-        } else {
-            // masses of (nearly) equal scores: every survivor gets the canonical chain, in place in global memory (Mt > CCAP > LCAP)
-            for (unsigned int p = tid; p < Mt; p += NT) {
-                const uint32_t row = ~(uint32_t)gsrc[p];
-                const float c = F32 ? canonical_dot_f32(xf32, dim, row, qv) : (xrow != nullptr ? canonical_dot_rows<8>(xrow, dim, row, qv) : canonical_dot_tiled(xt, ksteps, row, qv));
-                gsrc[p] = ((unsigned long long)ord_f32(c) << 32) | (unsigned long long)(~row);
-            }
-            __syncthreads();
-            CRH_SEL_STAMP(5);
-            select_tail<NT>(gsrc, Mt, false, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
-        }
-        CRH_SEL_STAMP(6);
+        unsigned long long *fq = fin + (size_t)q * qcap;
+        const unsigned int gbase = bcast[0];
+        for (unsigned int p = tid; p < Ms; p += NT) fq[gbase + p] = in_lds ? lkeys[p] : sk[p];
         return;
     }
     // Canonical re-score: one thread per survivor walks its row (96 pieces of 16 bytes, fetched 16 at a time, consumed in index
@@ -1774,6 +1699,178 @@ __global__ __launch_bounds__(1024) void k_select(const u32x2 *__restrict__ qlist
     CRH_SEL_STAMP(3);
     select_tail<NT>(sk, Ms, in_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
     CRH_SEL_STAMP(4);
+}
+
+// ------------------------------------------------------------------ final step behind the int8 scan
+
+// k_select<.., I8> left, per query, the fast scores of its survivors (keys (ord(fast) << 32) | ~row in `fkeys`, status->qsurv[q]
+// of them).  Here, gridDim.y workgroups per query:
+//   1. the k-th largest fast score; rows within `margin` of it are the only ones that can be in the canonical top-k (k_select's
+//      comment); every workgroup finds the same cut and takes every gridDim.y-th of those rows;
+//   2. the canonical score of its rows: the rows are STAGED in LDS first (all threads fetch, one round trip for the lot), then
+//      one thread per row walks the ordered chain out of LDS -- the chain used to sit behind a dozen dependent memory round
+//      trips per row (32 us for ~100 rows per query, stamps of round 4);
+//   3. keys (ord(score) << 32) | ~row published in `ckeys`; the workgroup that arrives last ranks them: exact top-k,
+//      descending score, ascending row, row_base added.
+template <bool F32>
+__global__ __launch_bounds__(256) void k_select_final(const unsigned long long *__restrict__ fkeys, unsigned long long *__restrict__ ckeys, int qcap,
+                                                      const float *__restrict__ qn, const u32x4 *__restrict__ xt, const float *__restrict__ xf32,
+                                                      const u32x4 *__restrict__ xrow, int dim, int ksteps, int k, float margin, int64_t row_base,
+                                                      float *__restrict__ out_scores, int64_t *__restrict__ out_rows, SearchStatus *__restrict__ status)
+{
+    constexpr int NT = 256;
+    constexpr unsigned int LCAP = 2048;             // keys ranked out of LDS
+    constexpr unsigned int MINE = 512;              // rows of one workgroup per round of canonical chains
+    constexpr int STAGE_U4 = 4096;                  // 64 KB of staged rows
+    __shared__ u32x4 stage[STAGE_U4];
+    __shared__ unsigned long long lkeys[LCAP];
+    __shared__ unsigned long long sortbuf[CRH_MAX_K];
+    __shared__ float qv[2048];
+    __shared__ unsigned int hist[(NT / 64) * 256];
+    __shared__ unsigned int fast[256 + 256 + 2 * (NT / 64) + 8];
+    __shared__ uint32_t mine[MINE];
+    __shared__ unsigned int bcast[2];
+    __shared__ unsigned int scount;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned int parts = gridDim.y, part = blockIdx.y;
+    const unsigned int Mt = status->qsurv[q];
+    if (Mt == 0u) return;                           // (no candidates: k_select has written the padding)
+    const unsigned long long *fq = fkeys + (size_t)q * qcap;
+    unsigned long long *cq = ckeys + (size_t)q * qcap;
+    float *os = out_scores + (size_t)q * k;
+    int64_t *orow = out_rows + (size_t)q * k;
+    for (int i = tid; i < dim; i += NT) qv[i] = qn[(size_t)q * dim + i];
+    uint32_t *fh = reinterpret_cast<uint32_t *>(lkeys);        // the fast scores' ord words, while they fit
+    const bool staged = Mt <= 2 * LCAP;
+    if (staged)
+        for (unsigned int i = tid; i < Mt; i += NT) fh[i] = (uint32_t)(fq[i] >> 32);
+    if (tid == 0) scount = 0u;
+    __syncthreads();
+    CRH_SEL_STAMP(4);
+    const unsigned int k3 = (unsigned int)k < Mt ? (unsigned int)k : Mt;
+    const uint32_t fkey = staged ? wg_kth_largest_fast<NT, 256, 256>([&](unsigned int i) { return fh[i]; }, Mt, k3, 0u, fast, hist, bcast)
+                                 : wg_kth_largest_fast<NT, 256, 256>([&](unsigned int i) { return (uint32_t)(fq[i] >> 32); }, Mt, k3, 0u, fast, hist, bcast);
+    const float fk = unord_f32(fkey);
+    const uint32_t cut = fk > -INFINITY ? ord_f32(fk - margin) : 0u;
+    __syncthreads();
+    // this workgroup's rows: every parts-th position of the list, those at or above the cut.  Windows of MINE * parts positions
+    // (so that `mine` holds a window's rows whatever the scores are -- masses of equal ones pass the cut together); a window's
+    // rows are staged and chained in rounds of as many rows as the stage holds.
+    const int cpr = F32 ? (dim >> 2) : (dim >> 3);  // 16-byte chunks per row
+    const int pitch = cpr + 1;                      // (+1 chunk: the lanes of a wave read different rows; a pitch of whole KiB would put them on the same banks)
+    const unsigned int rb = (unsigned int)(STAGE_U4 / pitch) < (unsigned int)NT ? (unsigned int)(STAGE_U4 / pitch) : (unsigned int)NT;
+    for (unsigned int w0 = 0; w0 < Mt; w0 += MINE * parts) {
+        if (tid == 0) scount = 0u;
+        __syncthreads();
+        const unsigned int w1 = w0 + MINE * parts < Mt ? w0 + MINE * parts : Mt;
+        for (unsigned int p = w0 + part + (unsigned int)tid * parts; p < w1; p += NT * parts) {
+            const unsigned long long key = fq[p];
+            if ((uint32_t)(key >> 32) >= cut) mine[atomicAdd(&scount, 1u)] = ~(uint32_t)key;
+        }
+        __syncthreads();
+        const unsigned int nw = scount;
+        if (nw == 0u) continue;                     // (workgroup-uniform)
+        if (tid == 0) bcast[0] = atomicAdd(&status->qsurv2[q], nw);
+        __syncthreads();
+        const unsigned int gbase = bcast[0];
+        for (unsigned int r0 = 0; r0 < nw; r0 += rb) {
+            const unsigned int nm = nw - r0 < rb ? nw - r0 : rb;
+            // stage the rows: chunk c of row j at stage[j * pitch + c]; every thread's loads of a sweep are requested together
+            const unsigned int total = nm * (unsigned int)cpr;
+            for (unsigned int e0 = tid; e0 < total; e0 += NT * 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned int e = e0 + j * NT;
+                    if (e < total) {
+                        const unsigned int rj = e / (unsigned int)cpr, c = e % (unsigned int)cpr;
+                        const uint32_t row = mine[r0 + rj];
+                        if (F32)
+                            v[j] = reinterpret_cast<const u32x4 *>(xf32 + (size_t)row * dim)[c];
+                        else if (xrow != nullptr)
+                            v[j] = xrow[(size_t)row * (size_t)cpr + c];
+                        else
+                            v[j] = xt[(size_t)(row >> 5) * ksteps * 64 + piece_off(c >> 1) + piece_slot(c & 1, (int)(row & 31u))];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned int e = e0 + j * NT;
+                    if (e < total) stage[(e / (unsigned int)cpr) * pitch + (e % (unsigned int)cpr)] = v[j];
+                }
+            }
+            __syncthreads();
+            // the ordered chain out of LDS: acc = acc + q_i * x_i, i ascending, product and sum rounded separately (orc_dot)
+            if ((unsigned int)tid < nm) {
+                const u32x4 *xr = stage + (unsigned int)tid * pitch;
+                float acc = 0.0f;
+                if (F32) {
+                    for (int c = 0; c < cpr; ++c) {
+                        const u32x4 pk = xr[c];
+                        const float *qq = qv + 4 * c;
+                        float p;
+                        p = qq[0] * bits_f32(pk.x);
+                        acc = acc + p;
+                        p = qq[1] * bits_f32(pk.y);
+                        acc = acc + p;
+                        p = qq[2] * bits_f32(pk.z);
+                        acc = acc + p;
+                        p = qq[3] * bits_f32(pk.w);
+                        acc = acc + p;
+                    }
+                } else {
+                    for (int c = 0; c < cpr; ++c) {
+                        const u32x4 pk = xr[c];
+                        const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+                        const float *qq = qv + 8 * c;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float p0_ = qq[2 * e] * bf16_bits_f32(w[e] & 0xffffu);
+                            acc = acc + p0_;
+                            float p1_ = qq[2 * e + 1] * bf16_bits_f32(w[e] >> 16);
+                            acc = acc + p1_;
+                        }
+                    }
+                }
+                const uint32_t row = mine[r0 + (unsigned int)tid];
+                cq[gbase + r0 + (unsigned int)tid] = ((unsigned long long)ord_f32(acc) << 32) | (unsigned long long)(~row);
+            }
+            __syncthreads();
+        }
+    }
+    CRH_SEL_STAMP(5);
+    // publish; the workgroup that arrives last ranks
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int arrived = __hip_atomic_fetch_add(&status->qdone2[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int total = 0u;
+        if (arrived == parts - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            total = __hip_atomic_load(&status->qsurv2[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bcast[0] = arrived == parts - 1u ? 1u : 0u;
+        bcast[1] = total;
+    }
+    __syncthreads();
+    if (bcast[0] == 0u) return;
+    const unsigned int Mc = bcast[1];
+    __syncthreads();
+    const bool all_lds = Mc <= LCAP;
+    if (all_lds) {
+        for (unsigned int p = tid; p < Mc; p += NT) lkeys[p] = cq[p];
+        __syncthreads();
+    }
+#ifdef CRH_FUSED_STAMPS
+    if (tid == 0 && blockIdx.x < 64) {
+        g_select_stamps[blockIdx.x * 16 + 10] = Mt;
+        g_select_stamps[blockIdx.x * 16 + 11] = Mc;
+    }
+#endif
+    select_tail<NT>(cq, Mc, all_lds, lkeys, sortbuf, hist, bcast, &scount, k, row_base, os, orow);
+    CRH_SEL_STAMP(6);
 }
 
 // ------------------------------------------------------------------ cross-shard merge
