@@ -356,6 +356,15 @@ def timed_search(torch, idx, qd, K, filters, steps, warmup, stream):
             "scan_launches": launches, "stats": idx.stats(), "scores": out_s[last], "rows": out_r[last]}
 
 
+def kernel_source_sha16() -> str:
+    """tools/summarize_prof.py stamps the counter pass with this fingerprint of the scan kernels' sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("crh_i8.hpp", "crh_kernels.hpp"):
+        h.update(open(os.path.join(ROOT, "code-rag_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def scan_kernel_name(D, mode):
     """The dominant kernel of a <= 64-query batch, by the nomination mode the index reports (crh_index_get_nomination):
     2 = the one-launch scan over the int8 copy, 1 = the one-launch scan over the bf16 tiles, 0 = the three-launch form."""
@@ -548,10 +557,14 @@ def run(args, json_fd) -> None:
 
     # HBM traffic of the scan kernel comes from PMC counters, which need their own rocprofv3 passes (tools/gpu_prof.sh);
     # the corrected per-launch figure of the committed pass is reported when it was taken at this corpus size
-    traffic = None
+    traffic, traffic_note = None, "no counter pass on record (profiles/pmc_scan.json)"
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_scan.json")))
-        if int(pmc.get("rows", -1)) == N and pmc.get("kernel") == scan_kernel_name(D, nom_mode):
+        if int(pmc.get("rows", -1)) != N or pmc.get("kernel") != scan_kernel_name(D, nom_mode):
+            traffic_note = f"the counter pass on record is of {pmc.get('kernel')} at {pmc.get('rows')} rows, not of this run's kernel / size"
+        elif pmc.get("kernel_source_sha16") != kernel_source_sha16():
+            traffic_note = "the kernel sources have changed since the counter pass on record was taken (tools/gpu_prof.sh takes a new one)"
+        else:
             traffic = float(pmc["hbm_read_bytes_corrected"]) + float(pmc["hbm_write_bytes"])
     except (OSError, ValueError, KeyError):
         pass
@@ -561,7 +574,8 @@ def run(args, json_fd) -> None:
     roof = scan_roofline(N, D, scan_ms, scan_launches, nom_mode)
     roof["traffic"] = traffic
     roof["whole_step_frac"] = roof["algorithmic_bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS   # the whole step on the pass's bytes
-    roof["traffic_source"] = "profiles/pmc_scan.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 per the gfx950 guide)" if traffic else None
+    roof["traffic_source"] = ("profiles/pmc_scan.json (separate rocprofv3 --pmc passes of this kernel's sources; FETCH_SIZE x2 per the gfx950 guide)"
+                              if traffic else traffic_note)
     out = {
         "metric": "top-k queries/s over 10Mx768 (cosine top-100, batch 64)",
         "value": value,
@@ -954,9 +968,18 @@ def embed_leg(np, torch, local_rank, n_chunks, rank, world, dist, cpu, cpu_secon
     log("encoder warm-up done")
     if dist is not None:
         dist.barrier()
+    # CODERAG_BENCH_EMBED_SYNC_EVERY=n (profiling runs only: tools/gpu_prof.sh sets it for the counter passes): wait for the
+    # stream every n batches.  The leg queues ~27 000 launches without waiting; under `rocprofv3 --pmc` a queue that deep
+    # crashed the profiled process inside the profiler's dispatch interception (profiles/README.md, "the --pmc SIGSEGV").
+    sync_every = int(os.environ.get("CODERAG_BENCH_EMBED_SYNC_EVERY", "0"))
+    if os.environ.get("CODERAG_BENCH_DUMP_MAPS"):          # load addresses of every library: what a crash's raw frames are symbolised against
+        with open("/proc/self/maps") as f_in, open(os.environ["CODERAG_BENCH_DUMP_MAPS"], "w") as f_out:
+            f_out.write("".join(ln for ln in f_in if ".so" in ln or "python" in ln))
     t0 = time.perf_counter()
-    for ids, off, Lmax in batches:
+    for bi, (ids, off, Lmax) in enumerate(batches):
         model.forward_packed(ids, off, Lmax)
+        if sync_every and (bi + 1) % sync_every == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

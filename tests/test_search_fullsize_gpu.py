@@ -193,7 +193,9 @@ def test_search_beside_an_encoder_forward_on_another_stream(gpu):
     rows = [np.concatenate([[0, 5, 2], rng.integers(16, cfg.vocab_size, int(L) - 4), [2]]).astype(np.int32) for L in lengths]
     flat, off, Lmax = model.pack_rows(rows, list(range(len(rows))))
     ids_d, off_d = torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev)
-    sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    # the searcher asks for a HIGH-PRIORITY stream: the device then takes its kernels ahead of the forward's ~1000 queued launches at
+    # the next kernel boundary (on equal priority a search was seen to sit behind the whole forward, 13 ms, without any wait timing out)
+    sA, sB = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev)
     out_s = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(8)]
     out_r = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(8)]
     with torch.cuda.stream(sB):

@@ -18,6 +18,17 @@ import re
 import sys
 
 
+def kernel_source_sha16() -> str:
+    """Fingerprint of the sources the scan kernels are built from: bench.py reports `roofline.traffic` from the committed counter
+    pass only while the kernels are still the ones that were profiled."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("crh_i8.hpp", "crh_kernels.hpp"):
+        h.update(open(os.path.join(root, "code-rag_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def short(name: str) -> str:
     name = re.sub(r"\(.*", "", name).replace("void ", "").strip()
     return name[-70:]
@@ -86,7 +97,7 @@ def main(src: str, dst: str, pmc_scan: str | None = None) -> None:
         name = norm(kn)
         rows = int(re.search(r"(\d+)x\d+ ", out["bench_line"]["config"]["workload"].split(": ", 1)[1]).group(1))
         json.dump({"source": f"{dst}.json ({src}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py)",
-                   "kernel": name, "rows": rows, "fetch_size_kib_mean": k["pmc"]["FETCH_SIZE"]["mean"],
+                   "kernel": name, "rows": rows, "kernel_source_sha16": kernel_source_sha16(), "fetch_size_kib_mean": k["pmc"]["FETCH_SIZE"]["mean"],
                    "write_size_kib_mean": k["pmc"]["WRITE_SIZE"]["mean"], "hbm_read_bytes_corrected": k["hbm_read_bytes_corrected"],
                    "hbm_write_bytes": k["hbm_write_bytes"],
                    "correction": "FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests of wide coalesced 16 B/lane streams at 64 B: "
