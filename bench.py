@@ -38,7 +38,7 @@ _T0 = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-ALL_LEGS = ("filtered", "scan_bf16", "wide", "config5", "clustered", "anisotropic", "f32_store", "embed", "c2", "embed_e2e", "c1", "cpu")
+ALL_LEGS = ("filtered", "scan_bf16", "wide", "config5", "clustered", "anisotropic", "f32_store", "embed", "c2", "embed_e2e", "index_e2e", "c1", "cpu")
 
 
 def log(msg: str) -> None:
@@ -189,7 +189,7 @@ def rehearse(args, json_fd) -> None:
     # the collectives of the legs an N > 1 run carries beside the headline (config5: the all-gather above + ONE all-reduce that
     # completes the packed side columns -- every candidate is owned by exactly one rank, the others contribute zeros; embed: no
     # data-path collective, barriers + max-over-ranks timing), with their layouts checked
-    legs = set(("config5", "embed") if args.legs is None else (x for x in args.legs.split(",") if x and x != "none"))
+    legs = set(("config5", "embed", "c2") if args.legs is None else (x for x in args.legs.split(",") if x and x != "none"))
     legs_ok = {}
     if "config5" in legs:
         n = B * K
@@ -209,6 +209,11 @@ def rehearse(args, json_fd) -> None:
         te = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         legs_ok["embed"] = bool(abs(float(te.item()) - 0.001 * world) < 1e-12)
+    if "c2" in legs:      # per-rank embed -> local shard (no collective) -> local top-k -> ONE all-gather of the records -> merge; parity flags meet in one all-reduce(MIN)
+        step(0)
+        flag = torch.tensor([1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        legs_ok["c2"] = bool(int(flag.item()) == 1 and all(int(all_r[r, 0, 1]) == 1 + r * n_local for r in range(world)))
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     devices = [None] * world                              # (the real run fills these from crh_device_info: a mis-pinned rank shows)
@@ -217,6 +222,10 @@ def rehearse(args, json_fd) -> None:
     dist.all_gather_into_tensor(ranks, torch.tensor([rank], dtype=torch.int64))
     per_rank = torch.zeros((world,), dtype=torch.float64)
     dist.all_gather_into_tensor(per_rank, torch.tensor([dt * 1e3 / max(1, args.steps)], dtype=torch.float64))
+    # how every rank's batches were nominated and what fell back (the real run: crh_index_get_nomination / crh_search_stats of
+    # each rank's shard): [mode, fallback_used] per rank in one all-gather -- here a recognisable stand-in, -1 - rank / rank
+    nom = torch.zeros((world, 2), dtype=torch.int64)
+    dist.all_gather_into_tensor(nom.view(-1), torch.tensor([-1 - rank, rank], dtype=torch.int64))
     if rank == 0:
         out = {"metric": "launcher rehearsal (gloo, CPU): no device work, not a measurement", "value": None, "unit": None,
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) * 1e3 / max(1, args.steps),
@@ -224,7 +233,8 @@ def rehearse(args, json_fd) -> None:
                "config": {"workload": f"rehearsal: {world} gloo ranks, {B}x{K} exchange records, {n_local} rows per rank"},
                "backend": "gloo", "collective_ranks": int(len(set(ranks.tolist()))), "rccl_ranks": None,
                "exchange_layout_ok": bool(layout_ok), "per_rank_step_ms": [float(v) for v in per_rank.tolist()],
-               "rows_per_gpu": n_local, "legs_rehearsed": legs_ok, "per_rank_device": devices}
+               "rows_per_gpu": n_local, "legs_rehearsed": legs_ok, "per_rank_device": devices,
+               "per_rank_nomination": [int(v) for v in nom[:, 0].tolist()], "per_rank_fallback_used": [int(v) for v in nom[:, 1].tolist()]}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.destroy_process_group()
     if not layout_ok or not all(legs_ok.values()):
@@ -441,7 +451,7 @@ def run(args, json_fd) -> None:
             dist = HostStagedCollectives(dist)
         else:
             dist.init_process_group("nccl", device_id=dev)
-    legs = set(ALL_LEGS if world == 1 else ("config5", "embed")) if args.legs is None else \
+    legs = set(ALL_LEGS if world == 1 else ("config5", "embed", "c2")) if args.legs is None else \
         set(x for x in args.legs.split(",") if x and x != "none")
     unknown = legs - set(ALL_LEGS)
     if unknown:
@@ -449,7 +459,7 @@ def run(args, json_fd) -> None:
     if args.no_cpu_baseline or world > 1:
         legs -= {"cpu"}
     if world > 1:
-        legs -= {"c1", "c2", "embed_e2e", "f32_store", "filtered", "scan_bf16", "wide", "clustered", "anisotropic"}      # one-GPU verification legs
+        legs -= {"c1", "embed_e2e", "index_e2e", "f32_store", "filtered", "scan_bf16", "wide", "clustered", "anisotropic"}      # one-GPU verification legs
 
     D, N, B, K = 768, args.rows, args.queries, args.k
     if args.scaling == "strong":
@@ -521,7 +531,7 @@ def run(args, json_fd) -> None:
 
     # ---- what actually took part in the exchange (N>1): distinct ranks seen through a real all-gather, per-rank step times,
     # and the merged list against a sort of the gathered lists (score descending, lower global row first)
-    rccl_ranks, per_rank_ms, merge_ok, per_rank_device = None, None, None, None
+    rccl_ranks, per_rank_ms, merge_ok, per_rank_device, per_rank_nom = None, None, None, None, None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -532,6 +542,9 @@ def run(args, json_fd) -> None:
         pr = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(pr, torch.tensor([float(np.median(per_step))], dtype=torch.float64, device=dev))
         per_rank_ms = [float(v) for v in pr.tolist()]
+        nomt = torch.zeros((dist.get_world_size(), 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(nomt.view(-1), torch.tensor([int(nom_mode), int(stats["fallback_used"])], dtype=torch.int64, device=dev))
+        per_rank_nom = [[int(a), int(b)] for a, b in nomt.tolist()]
         info = ffi.device_info(local_rank)
         per_rank_device = [None] * dist.get_world_size()
         me = {"rank": rank, "local_rank": local_rank, "device_name": info["name"], "arch": info["arch"], "hbm_bytes": info["hbm_bytes"],
@@ -597,6 +610,9 @@ def run(args, json_fd) -> None:
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
         "per_rank_device": per_rank_device,
+        # (2 = every batch of that rank was nominated from its int8 copy; fallback bits: 1 buffers regrown, 2 a grid-wide wait timed out, 4 a batch went to the bf16 scan)
+        "per_rank_nomination": [a for a, _ in per_rank_nom] if per_rank_nom else None,
+        "per_rank_fallback_used": [b for _, b in per_rank_nom] if per_rank_nom else None,
         "rccl_ranks": rccl_ranks if args.backend == "nccl" else None,
         "collective_ranks": rccl_ranks, "backend": args.backend if dist is not None else None,
         "exchange_ms_device": (dict(pct(exchange), what="1 RCCL all-gather of the [scores | rows] records + k_merge_topk, rank 0")
@@ -767,9 +783,10 @@ def run(args, json_fd) -> None:
         ("cpu" in legs), args.cpu_seconds)
     if args.embed_chunks <= 0:
         legs.discard("c2")
-    leg("c2", c2_leg, np, torch, ffi, local_rank, args.embed_chunks, rank, B, K, args.c2_parity_chunks)
+    leg("c2", c2_leg, np, torch, ffi, local_rank, args.embed_chunks, rank, B, K, args.c2_parity_chunks if world == 1 else 0, dist, world)
     ckpt = {}
     leg("embed_e2e", embed_e2e_leg, np, torch, local_rank, args.e2e_texts, ckpt)
+    leg("index_e2e", index_e2e_leg, np, torch, local_rank, ckpt)
     leg("c1", c1_leg, np, torch, local_rank, ckpt, args.cpu_seconds * 4 if "cpu" in legs else 0.0)
     if "cpu" in legs and rank == 0:
         leg("cpu", cpu_baseline, np, B, K, D, args.cpu_seconds, key="cpu_baseline")
@@ -1028,7 +1045,7 @@ def synth_chunk_ids(np, cfg, lengths, rng):
             else np.asarray([0, 5, 2, 2][:int(n)], np.int32) for n in lengths]
 
 
-def c2_leg(np, torch, ffi, local_rank, n_chunks, rank, B, K, parity_chunks):
+def c2_leg(np, torch, ffi, local_rank, n_chunks, rank, B, K, parity_chunks, dist=None, world=1):
     """BASELINE configs[1] as the ONE pipeline it names: n synthetic code chunks (the embed leg's seed and length mix) -> packed
     HIP encoder -> device-to-device crh_index_append -> batch-64 exact top-100 over the EMBEDDED vectors (the reference's
     embeddings/indexer.py:66-85 + query/vector_search.py:60-116 with the host round trips taken out).  Encoder outputs are
@@ -1071,6 +1088,76 @@ def c2_leg(np, torch, ffi, local_rank, n_chunks, rank, B, K, parity_chunks):
            "data": "synthetic ids + seeded random RoBERTa-base-geometry weights (no checkpoint offline); queries: 32 corpus chunks with 10 % of "
                    "their tokens replaced + 32 fresh rows"}
     stores = {}
+    multi = dist is not None and world > 1
+    if multi:
+        # N > 1 (embed row): every rank embeds ITS OWN n chunks (seed 1234 + rank) straight into its local shard -- no
+        # collective, no vector crosses ranks -- the 64 queries are the same on every rank, each rank's exact local top-k (global
+        # rows rank * n + local) meets the others in ONE all-gather and is merged on every rank: the sharded top-100 over world * n
+        # embedded chunks.  Parity: every rank's local list against the oracle on ITS vectors, the merged list against a sort of
+        # the gathered lists (the exact top-k of a union is the merge of the exact per-shard top-k).
+        idx = ffi.Index(768, ffi.DTYPE_BF16, capacity_rows=n_chunks, n_code_cols=1, device=local_rank)
+        for ids, off, Lmax, nr in batches[:2]:
+            model.forward_packed(ids, off, Lmax)
+        torch.cuda.synchronize()
+        dist.barrier()
+        outs = []
+        t0 = time.perf_counter()
+        for ids, off, Lmax, nr in batches:
+            out = model.forward_packed(ids, off, Lmax)
+            idx.append(out, codes=codes[:nr], stream=stream)
+            outs.append(out)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_index = time.perf_counter() - t0
+        tt = torch.tensor([t_index], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_index = float(tt.item())
+        qd = model.embed_ids([r.tolist() for r in q_rows])
+        local, loc_s, loc_r, gathered, gat_s, gat_r = ffi.topk_exchange_buffers(torch, world, B, K, dev)
+        mer_s = torch.empty((B, K), dtype=torch.float32, device=dev)
+        mer_r = torch.empty((B, K), dtype=torch.int64, device=dev)
+
+        def once():
+            idx.search(qd, K, row_base=rank * n_chunks, out_scores=loc_s, out_rows=loc_r, stream=stream)
+            dist.all_gather_into_tensor(gathered.view(-1), local)
+            ffi.merge_topk(gat_s, gat_r, mer_s, mer_r, stream)
+        for _ in range(3):
+            once()
+        idx.search_finish(stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            once()
+        idx.search_finish(stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_search = (time.perf_counter() - t0) / 20
+        vecs = torch.cat(outs).cpu().numpy()
+        es, er = osr.cosine_search(vecs, qd.cpu().numpy(), K, bf16=True)
+        local_ok = bool(np.array_equal(loc_r.cpu().numpy() - rank * n_chunks, er) and np.array_equal(loc_s.cpu().numpy().view(np.uint32), es.view(np.uint32)))
+        cat_s, cat_r = gat_s.permute(1, 0, 2).reshape(B, -1), gat_r.permute(1, 0, 2).reshape(B, -1)
+        o1 = torch.argsort(cat_r, dim=1, stable=True)
+        o2 = torch.argsort(torch.gather(cat_s, 1, o1), dim=1, descending=True, stable=True)
+        order = torch.gather(o1, 1, o2)[:, :K]
+        merged_ok = bool(torch.equal(torch.gather(cat_r, 1, order), mer_r) and torch.equal(torch.gather(cat_s, 1, order), mer_s))
+        flag = torch.tensor([int(local_ok and merged_ok)], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        owners = np.bincount((mer_r.cpu().numpy().reshape(-1) // n_chunks).astype(np.int64), minlength=world).tolist()
+        stats = idx.stats()
+        idx.close()
+        if rank != 0:
+            return None
+        res.update({"workload": f"{world} ranks x {n_chunks} synthetic code chunks: every rank embeds its own chunks into its local shard (no collective) -> "
+                                f"batch-{B} exact top-{K} over the {world * n_chunks} embedded vectors (per-rank scan, one all-gather, merge)",
+                    "value": world * n_chunks / t_index, "unit": "chunks/s (embed + index, all ranks)", "seconds_embed_plus_index": t_index,
+                    "search": {"ms_per_batch": t_search * 1e3, "queries_per_s": B / t_search}, "search_stats_rank0": stats,
+                    "merged_hits_by_owning_rank": owners,
+                    "parity": {"every_rank_local_topk_bit_exact_vs_oracle_on_its_vectors_and_merge_equals_sorted_concat": bool(int(flag.item()) == 1),
+                               "what": "rank-local ids and f32 score bits vs oracle/search on the rank's own embedded vectors; merged list vs a sort of the all-gathered lists; "
+                                       "the flags of all ranks meet in one all-reduce(MIN)"}})
+        log(f"c2 (x{world}): {res['value']:.0f} chunks/s embed+index over all ranks, sharded search {t_search * 1e3:.3f} ms/batch, parity {int(flag.item()) == 1}")
+        return res
     for name, dtype in (("bf16", ffi.DTYPE_BF16), ("f32", ffi.DTYPE_F32)):
         idx = ffi.Index(768, dtype, capacity_rows=n_chunks, n_code_cols=1, device=local_rank)
         for ids, off, Lmax, nr in batches[:2]:
@@ -1293,6 +1380,64 @@ def embed_e2e_leg(np, torch, local_rank, n_texts, box):
                          "frac": flops / t_one / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops": flops,
                          "note": "end to end: tokenizer, H2D, forward, D2H and .tolist() are all inside the time"},
             "parity": {"min_cosine_same_text_across_batch_shapes": cos}}
+
+
+def index_e2e_leg(np, torch, local_rank, box, n_files=600):
+    """Indexing END TO END through the reference-shaped surfaces only (src/lattice/embeddings/indexer.py:46-119,
+    pipeline/orchestrator.py:652-656): parsed files -> CodeChunker -> Embedder -> HipUniXcoderProvider (native tokenizer, HIP
+    encoder) -> HipVectorStore.upsert.  `sequential`: VectorIndexer.index_files as the reference runs it (per file: update
+    check, delete, chunk, embed_with_progress, upsert).  `value`: VectorIndexer.index_files_batched -- the same outcome in one
+    pass (one update check, one delete job, all files chunked, ONE coalesced embedding submission handed over as an array, ONE
+    upsert).  Both runs are checked against each other: same chunk count, and a stored chunk's text finds that chunk."""
+    import asyncio
+    import types
+    from pathlib import Path
+    from coderag_amd.embedder import Embedder
+    from coderag_amd.indexer import CodeChunker, VectorIndexer
+    from coderag_amd.providers import HipUniXcoderProvider, ProviderConfig
+    from coderag_amd.store import HipVectorStore
+    d = synth_checkpoint(np, torch, box)
+    os.environ["CODERAG_HIP_DEVICE"] = str(local_rank)
+    lines = "\n".join(open(f, encoding="utf-8", errors="ignore").read() for f in _source_files() if f.endswith(".py")).split("\n")
+    rng = np.random.default_rng(0)
+
+    def parsed_file(i):
+        ents = []
+        for j in range(int(rng.integers(8, 40))):
+            a = int(rng.integers(0, len(lines) - 40))
+            code = "\n".join(lines[a:a + int(rng.integers(6, 40))])
+            ents.append(types.SimpleNamespace(type=types.SimpleNamespace(value="function"), name=f"fn_{i}_{j}", qualified_name=f"mod{i}.fn_{i}_{j}",
+                                              signature=f"def fn_{i}_{j}(x)", docstring="Does things.", code=code, start_line=10 * j + 1, end_line=10 * j + 9))
+        info = types.SimpleNamespace(path=Path(f"/proj/mod{i}.py"), content_hash=f"h{i}", language=types.SimpleNamespace(value="python"))
+        return types.SimpleNamespace(file_info=info, content="", all_entities=ents)
+    files = [parsed_file(i) for i in range(n_files)]
+    provider = box.get("provider") or HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model=d))
+    embedder = Embedder(provider_instance=provider)
+    probe = files[7].all_entities[3]
+    probe_text = "\n".join([probe.signature, f'"""{probe.docstring}"""', probe.code])
+
+    async def one(batched):
+        async with HipVectorStore(device=local_rank, dim=768, dtype="bf16", initial_capacity=1 << 16) as store:
+            await store.create_collections()
+            indexer = VectorIndexer(store, embedder, CodeChunker(max_tokens=1000, overlap_tokens=200))
+            t0 = time.perf_counter()
+            n = await (indexer.index_files_batched if batched else indexer.index_files)(files, project_name="proj")
+            dt = time.perf_counter() - t0
+            qv = await embedder.embed(probe_text)
+            top = (await store.search("code_chunks", qv, limit=1))[0]
+            again = await (indexer.index_files_batched if batched else indexer.index_files)(files[:50], project_name="proj")      # unchanged: skipped
+            return n, dt, (top["payload"]["entity_name"], top["payload"]["file_path"]), again, (await store.get_collection_info("code_chunks")).points_count
+    asyncio.run(embedder.embed_batch(["warm up"] * 64))
+    n_b, t_b, top_b, again_b, count_b = asyncio.run(one(True))
+    n_s, t_s, top_s, again_s, count_s = asyncio.run(one(False))
+    same = bool(n_b == n_s == count_b == count_s and top_b == top_s == ("mod7.fn_7_3", "/proj/mod7.py") and again_b == again_s == 0)
+    log(f"index_e2e: batched {n_b / t_b:.0f} chunks/s, sequential (the reference's flow) {n_s / t_s:.0f} chunks/s, same outcome {same}")
+    return {"metric": "chunks indexed/s through VectorIndexer -> CodeChunker -> Embedder -> provider -> HipVectorStore.upsert", "value": n_b / t_b,
+            "unit": "chunks/s", "files": n_files, "chunks": n_b, "seconds": t_b,
+            "flow": "VectorIndexer.index_files_batched: one update check, one delete job, all files chunked, one coalesced embedding submission (float32 array), one upsert",
+            "sequential": {"value": n_s / t_s, "seconds": t_s, "flow": "VectorIndexer.index_files (indexer.py:96-119): per file update check, delete, chunk, embed_with_progress, upsert"},
+            "data": "600 synthetic parsed files of 8-40 entities cut from this repo's Python sources; byte-level BPE vocabulary (8000) trained on them; seeded 12-layer weights",
+            "parity": {"batched_equals_sequential": same, "what": "chunk counts, collection size, a stored chunk's own text finds that chunk first, unchanged files are skipped on a second run"}}
 
 
 def code_chunks(limit: int = 1000):

@@ -45,5 +45,24 @@ class Embedder:
         logger.info(f"Generated {len(vectors)} embeddings across {(total + batch_size - 1) // batch_size} batches")
         return vectors
 
+    async def embed_array(self, texts: Sequence[str]):
+        """All texts in ONE coalesced submission, returned as a float32 array [n, dim] -- no Python float lists between the
+        encoder and the store (the reference's ``list[list[float]]`` costs as much as the GPU forward at this size).  Not in the
+        reference; ``VectorIndexer.index_files_batched`` uses it.  A provider without an array path goes through
+        :meth:`embed_batch`."""
+        import asyncio
+        import numpy as np
+        items = list(texts)
+        fn = getattr(self._provider, "embed_texts_sync", None)
+        if fn is None:
+            return np.asarray(await self._provider.embed_batch(items, batch_size=max(1, len(items))), dtype=np.float32)
+        loop = asyncio.get_running_loop()
+        executor = getattr(self._provider, "_executor", None)          # the provider's own worker thread: one thread drives the encoder
+        return await loop.run_in_executor(executor, fn, items)
+
+    @property
+    def provider(self) -> BaseEmbeddingProvider:
+        return self._provider
+
 
 OpenAIEmbedder = Embedder  # alias kept by the reference (embedder.py:73)

@@ -159,6 +159,19 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
         except Exception as e:
             raise EmbeddingError("HIP UniXcoder embedding failed", cause=e)
 
+    def embed_texts_sync(self, texts: list[str]):
+        """Blocking form for a caller that already sits on a worker thread -- ``HipVectorStore.upsert(vectors=None, texts=...,
+        embed=provider.embed_texts_sync)``: the store routes the rows to their shards first and every process embeds only its
+        own share.  Returns a float32 array [n, 768] (no Python float lists)."""
+        import numpy as np
+        if not texts:
+            return np.zeros((0, self.EMBEDDING_DIM), np.float32)
+        try:
+            self.submissions += 1
+            return np.asarray(self._load().embed_texts(list(texts), max_length=self.max_length, rows="numpy"), dtype=np.float32)
+        except Exception as e:
+            raise EmbeddingError("HIP UniXcoder embedding failed", cause=e)
+
     async def _embed_impl(self, texts: list[str]) -> list[list[float]]:
         loop = asyncio.get_running_loop()
         if not self.dynamic_batching:

@@ -7,9 +7,11 @@ delete / count / match by filter, search, compact, save / load -- and spreads th
 * ``backend="local"``: all shards live in this process (on one device, or one per listed device).  What a one-GPU box can run;
   the search is n scans -> ``crh_merge_topk_strided`` on the device.
 * ``backend="dist"``: one process per GPU under ``torch.distributed`` (``nccl`` = RCCL over xGMI); every rank makes the SAME
-  calls (the host tables are replicated, the vectors are not) and owns shard ``rank``.  The search is the path of
-  ``sharded.ShardedIndex``: local scan with ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.
-  Control-plane results (counts, matching rows, compaction maps) travel as small host objects.
+  calls and owns shard ``rank``: its rows' vectors, and -- since round 4 -- their embedding work and their payload TEXT
+  (``append`` takes the rows of the owned shards only; ``exchange_bytes`` completes what only an owner holds).  Ids, the coded
+  payload columns and the slot maps stay replicated.  The search is the path of ``sharded.ShardedIndex``: local scan with
+  ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.  Control-plane results (counts, matching
+  rows, compaction maps) travel as small host objects; what a search returns travels in tensor collectives only.
 
 Rows are dealt to the shards in blocks of ``block`` rows, round robin, so shards stay balanced under incremental upserts.
 A row's global id is ``shard * STRIDE + local row`` (``STRIDE`` = 2^32, a ``crh_index`` holds at most 2^31 rows): stable under
@@ -27,6 +29,15 @@ import numpy as np
 from . import ffi
 
 STRIDE = 1 << 32
+
+
+class AppendFailed(RuntimeError):
+    """An append that failed after some shards had taken their rows: ``done`` = {shard: (first local row, rows)} of the rows
+    that ARE on the device (tombstoned by the time this is raised); the caller's slot maps must step over them."""
+
+    def __init__(self, cause: BaseException, done: dict[int, tuple[int, int]]):
+        super().__init__(f"append failed: {cause!r}")
+        self.cause, self.done = cause, done
 
 
 class ShardSet:
@@ -82,42 +93,103 @@ class ShardSet:
         self._next_block = int((self._next_block + blocks) % self.ns)
         return np.repeat(sh, self.block)[:n].astype(np.int32)
 
-    def append(self, vecs, codes, preprocessed: bool = False, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
-        """Append n rows (numpy [n, dim] or a CUDA tensor; codes numpy [n, cols] or None).  Returns (shard [n], local row [n])."""
-        n = int(vecs.shape[0])
-        shard = self.route(n)
+    def append(self, vecs, codes, preprocessed: bool = False, stream: int = 0, shard: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
+        """Append n rows.  ``vecs``: numpy [n, dim] or a CUDA tensor holding ALL n rows -- or, with ``shard`` (the routing of the
+        n rows, from :meth:`route`), a dict {owned shard: its rows in order}: the form a rank uses when it has embedded only its
+        own share.  ``codes``: numpy [n, cols] for all n rows, or None.  Returns (shard [n], local row [n]).
+
+        Nothing is committed until every owned shard has the capacity; if a shard's append still fails, the rows the earlier
+        shards took are tombstoned and :class:`AppendFailed` tells the caller where they sit.  Under backend "dist" the ranks
+        agree on the outcome before anyone returns."""
+        per_shard = isinstance(vecs, dict)
+        if per_shard and shard is None:
+            raise ValueError("per-shard rows need the routing they were cut by")
+        n = int(len(shard) if shard is not None else vecs.shape[0])
+        saved_next = self._next_block
+        if shard is None:
+            shard = self.route(n)
         local = np.empty((n,), np.int64)
-        on_dev = not isinstance(vecs, np.ndarray)
+        plan = []                                     # (shard, rows of the call, first local row)
         for s in range(self.ns):
-            sel = np.flatnonzero(shard == s) if self.ns > 1 else None
-            m = n if sel is None else int(sel.size)
-            if m == 0:
-                continue
-            first = self.rows[s]
-            if sel is None:
-                local[:] = first + np.arange(n)
-            else:
-                local[sel] = first + np.arange(m)
-            if s in self.index:
+            sel = np.flatnonzero(shard == s) if self.ns > 1 else np.arange(n)
+            if sel.size:
+                local[sel] = self.rows[s] + np.arange(sel.size)
+                plan.append((s, sel, self.rows[s]))
+        done: dict[int, tuple[int, int]] = {}
+        failure: BaseException | None = None
+        try:
+            for s, sel, first in plan:                # capacity first, on every owned shard: a refusal here leaves nothing behind
+                if s in self.index and first + sel.size > self.index[s].capacity_rows:
+                    self.index[s].reserve(max(first + int(sel.size), 2 * self.index[s].capacity_rows))
+            for s, sel, first in plan:
+                if s not in self.index:
+                    continue
                 ix = self.index[s]
-                if first + m > ix.capacity_rows:
-                    ix.reserve(max(first + m, 2 * ix.capacity_rows))
-                if sel is None:
-                    v, c = vecs, codes
-                elif on_dev:
+                if per_shard:
+                    v = vecs[s]
+                elif self.ns == 1:
+                    v = vecs
+                elif isinstance(vecs, np.ndarray):
+                    v = vecs[sel]
+                else:
                     import torch
                     v = vecs.index_select(0, torch.from_numpy(sel).to(vecs.device))
-                    c = codes[sel] if codes is not None else None
-                else:
-                    v, c = vecs[sel], (codes[sel] if codes is not None else None)
+                if int(v.shape[0]) != sel.size:
+                    raise ValueError(f"shard {s}: {int(v.shape[0])} rows for {sel.size} routed to it")
+                c = None if codes is None else (codes if self.ns == 1 else codes[sel])
+                on_dev = not isinstance(v, np.ndarray)
                 if on_dev and c is not None:
                     import torch
                     c = torch.from_numpy(np.ascontiguousarray(c)).to(v.device)
                 got = ix.append(v, c, stream=stream, preprocessed=preprocessed) if on_dev else ix.append(v, c, preprocessed=preprocessed)
+                done[s] = (int(got), int(sel.size))
                 if got != first:
                     raise RuntimeError(f"shard {s}: append landed at row {got}, the bookkeeping expected {first}")
-            self.rows[s] = first + m
+        except BaseException as e:  # noqa: BLE001 -- rolled back below, then re-raised
+            failure = e
+        if self.dist is not None:                     # one rank's failure is everybody's: the replicated bookkeeping must not part ways
+            outcomes = self._everyone(None if failure is None else repr(failure))
+            if failure is None and any(o is not None for o in outcomes):
+                failure = RuntimeError(f"append failed on another rank: {[o for o in outcomes if o is not None][0]}")
+        if failure is not None:
+            for s, (got, m) in done.items():          # the rows that did land: dead, and accounted for
+                self.index[s].tombstone(np.arange(got, got + m, dtype=np.int64))
+            all_done: dict[int, tuple[int, int]] = {}
+            for part in self._everyone(done):
+                all_done.update(part)
+            for s, (got, m) in all_done.items():
+                self.rows[s] = got + m
+            self._next_block = saved_next if not all_done else self._next_block
+            if all_done:
+                raise AppendFailed(failure, all_done) from failure
+            raise failure
+        for s, sel, first in plan:
+            self.rows[s] = first + int(sel.size)
         return shard, local
+
+    def exchange_bytes(self, parts: list) -> list:
+        """``parts[i]``: bytes where THIS rank holds item i, None elsewhere (every item is held by exactly one rank, and every rank
+        passes a list of the same length).  Returns the complete list on every rank -- two tensor all-reduces (lengths, then one
+        byte buffer), no pickled objects: what a search's hits need from the ranks that own their payload text."""
+        if self.dist is None:
+            return parts
+        import torch
+        dev = torch.device("cuda", self.device) if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        lens = torch.tensor([0 if p is None else len(p) for p in parts], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(lens, op=self.dist.ReduceOp.SUM, group=self.group)
+        lens_h = lens.cpu().numpy()
+        off = np.zeros((len(parts) + 1,), np.int64)
+        np.cumsum(lens_h, out=off[1:])
+        buf = np.zeros((max(int(off[-1]), 1),), np.uint8)
+        for i, p in enumerate(parts):
+            if p:
+                if len(p) != int(lens_h[i]):
+                    raise RuntimeError("exchange_bytes: an item is held by more than one rank")
+                buf[off[i]:off[i + 1]] = np.frombuffer(p, np.uint8)
+        t = torch.from_numpy(buf).to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        out_b = t.cpu().numpy().tobytes()
+        return [out_b[off[i]:off[i + 1]] for i in range(len(parts))]
 
     def tombstone(self, shard: np.ndarray, local: np.ndarray) -> None:
         for s, ix in self.index.items():

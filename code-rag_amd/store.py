@@ -27,8 +27,8 @@ import numpy as np
 from . import ffi
 from .errors import VectorStoreError
 from .settings import get_settings
-from .shards import STRIDE as SHARD_STRIDE, ShardSet
-from .tables import DICT_KEYS, IdTable, PayloadTable
+from .shards import STRIDE as SHARD_STRIDE, AppendFailed, ShardSet
+from .tables import DICT_KEYS, TEXT_KEYS, IdTable, PayloadTable
 
 logger = logging.getLogger(__name__)
 
@@ -96,6 +96,10 @@ class _Collection:
         self._device = device
         self.compact_dead_fraction, self.compact_min_dead = compact_dead_fraction, compact_min_dead
         self.compactions = 0
+        # One process per shard (backend "dist"): a rank keeps the payload TEXT (content, summary: 4.2 of the 5.2 GB of host
+        # tables per 10M chunks) of its OWN rows only -- everybody else stores an empty string there -- and a hit's payload comes
+        # from the rank that owns the row (payloads_of: one byte exchange per search, shards.ShardSet.exchange_bytes).
+        self.partial = backend == "dist" and nshards > 1
 
     @property
     def index(self):
@@ -204,38 +208,89 @@ class _Collection:
         self.maybe_compact()
         return n
 
-    def upsert(self, ids, vectors, payloads, preprocessed: bool = False) -> None:
+    def upsert(self, ids, vectors, payloads, preprocessed: bool = False, texts=None, embed=None) -> None:
         """``vectors``: list of float lists (what the reference passes), a float32 ndarray [n, dim], or a CUDA tensor [n, dim]
-        on this collection's device (no host round trip)."""
+        on this collection's device (no host round trip) -- or None with ``texts`` and ``embed`` (``embed(list[str])`` -> ndarray /
+        CUDA tensor [m, dim]): the rows are routed first and every process embeds only the texts of the shards it owns, straight
+        into them (embeddings/indexer.py:66-85 with the embedding work sharded like the rows: SURVEY 8(e), embed row)."""
         n = len(ids)
         if n == 0:
             return
-        on_dev = not isinstance(vectors, (list, tuple, np.ndarray)) and bool(getattr(vectors, "is_cuda", False))
-        vecs = vectors if on_dev else np.asarray(vectors, dtype=np.float32)
-        if vecs.ndim != 2 or int(vecs.shape[0]) != n or len(payloads) != n:
-            raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {tuple(vecs.shape)}, {len(payloads)})")
-        if int(vecs.shape[1]) != self.shards.dim:
-            raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.shards.dim}")
+        lazy = vectors is None
+        if lazy:
+            if texts is None or embed is None or len(texts) != n:
+                raise ValueError("upsert without vectors needs one text per id and an embed callable")
+            vecs, on_dev = None, False
+        else:
+            on_dev = not isinstance(vectors, (list, tuple, np.ndarray)) and bool(getattr(vectors, "is_cuda", False))
+            vecs = vectors if on_dev else np.asarray(vectors, dtype=np.float32)
+            if vecs.ndim != 2 or int(vecs.shape[0]) != n:
+                raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n}, {tuple(vecs.shape)}, {len(payloads)})")
+            if int(vecs.shape[1]) != self.shards.dim:
+                raise ValueError(f"vector dimension {vecs.shape[1]} does not match the collection's {self.shards.dim}")
+        if len(payloads) != n:
+            raise ValueError(f"upsert needs equally many ids, vectors and payloads (got {n} ids, {len(payloads)} payloads)")
         ids = [str(i) for i in ids]
         last = dict(zip(ids, range(n)))                       # a repeated id inside one call: last one wins
         if len(last) != n:
             keep = sorted(last.values())
             ids, payloads = [ids[i] for i in keep], [payloads[i] for i in keep]
-            vecs = vecs[keep] if not on_dev else vecs[ffi_index_tensor(vecs, keep)]
+            if lazy:
+                texts = [texts[i] for i in keep]
+            else:
+                vecs = vecs[keep] if not on_dev else vecs[ffi_index_tensor(vecs, keep)]
             n = len(keep)
         n0 = self.payloads.n
-        self.payloads.extend(payloads)
+        saved_next = self.shards._next_block
+        shard = self.shards.route(n)
+        if self.partial:                                      # the text of rows other ranks own stays with them
+            owned = np.isin(shard, self.shards.owned)
+            stored = [p if o else {k: ("" if k in TEXT_KEYS and isinstance(v, str) else v) for k, v in p.items()} for p, o in zip(payloads, owned)]
+        else:
+            stored = payloads
+        self.payloads.extend(stored)
+        orphans: dict[int, tuple[int, int]] = {}
         try:
             codes = self.payloads.device_codes(self.keys, n0, n0 + n) if self.keys else None
-            if on_dev:
+            if lazy:
+                per_shard = {}
+                for sh in self.shards.owned:
+                    sel = np.flatnonzero(shard == sh)
+                    if sel.size:
+                        v = embed([texts[i] for i in sel])
+                        v = v if bool(getattr(v, "is_cuda", False)) else np.asarray(v, dtype=np.float32)
+                        if v.ndim != 2 or int(v.shape[0]) != sel.size or int(v.shape[1]) != self.shards.dim:
+                            raise ValueError(f"embed returned {tuple(v.shape)} for {sel.size} texts of dimension {self.shards.dim}")
+                        per_shard[sh] = v
+                dev_rows = [v for v in per_shard.values() if not isinstance(v, np.ndarray)]
+                if dev_rows:
+                    import torch
+                    per_shard = {sh: (v.contiguous() if v.dtype == torch.float32 else v.float().contiguous()) if not isinstance(v, np.ndarray) else v
+                                 for sh, v in per_shard.items()}
+                    _, local = self.shards.append(per_shard, codes, preprocessed, stream=ffi.current_stream(dev_rows[0].device), shard=shard)
+                    torch.cuda.current_stream(dev_rows[0].device).synchronize()
+                else:
+                    _, local = self.shards.append(per_shard, codes, preprocessed, shard=shard)
+            elif on_dev:
                 import torch
                 vecs = vecs.contiguous() if vecs.dtype == torch.float32 else vecs.float().contiguous()
-                shard, local = self.shards.append(vecs, codes, preprocessed, stream=ffi.current_stream(vecs.device))
+                _, local = self.shards.append(vecs, codes, preprocessed, stream=ffi.current_stream(vecs.device), shard=shard)
                 torch.cuda.current_stream(vecs.device).synchronize()      # the caller may free / reuse its tensor right away
             else:
-                shard, local = self.shards.append(vecs, codes, preprocessed)
+                _, local = self.shards.append(vecs, codes, preprocessed, shard=shard)
+        except AppendFailed as e:
+            # some shards took their rows before another refused: those rows are dead on the device and have no slot -- the
+            # maps step over them (-1), the tables go back
+            self.payloads.truncate(n0)
+            if self.shards.ns > 1:
+                for sh, (_, m) in e.done.items():
+                    self.slot_of[sh] = np.concatenate([self.slot_of[sh], np.full((m,), -1, np.int64)])
+            else:
+                raise RuntimeError("a one-shard collection cannot lose an append half-way") from e
+            raise e.cause
         except Exception:
             self.payloads.truncate(n0)                        # nothing was stored: the tables go back to where they were
+            self.shards._next_block = saved_next
             raise
         replaced = self.ids.extend(ids)                       # slots these ids occupied before (-1: new)
         if self.shards.ns > 1:
@@ -251,7 +306,26 @@ class _Collection:
             self.maybe_compact()
 
     def hit(self, slot: int, score: float) -> dict[str, Any]:
-        return {"id": self.ids.get(slot), "score": score, "payload": self.payloads.get(slot)}
+        return {"id": self.ids.get(slot), "score": score, "payload": self.payloads_of([slot])[0]}
+
+    def payloads_of(self, slots) -> list[dict[str, Any]]:
+        """The stored payload dictionaries of ``slots`` (every process passes the same list).  With one process per shard only a
+        row's OWNER holds its text: each rank serialises the payloads of the slots it owns and ONE byte exchange completes the
+        list everywhere (``ShardSet.exchange_bytes``: two tensor all-reduces)."""
+        slots = [int(t) for t in slots]
+        if not self.partial:
+            return [self.payloads.get(t) for t in slots]
+        import json
+        mine = set(self.shards.owned)
+        parts = [json.dumps(self.payloads.get(t), default=repr, ensure_ascii=False).encode("utf-8", "surrogatepass") if int(self.row_shard[t]) in mine else None
+                 for t in slots]
+        return [json.loads(b.decode("utf-8", "surrogatepass")) for b in self.shards.exchange_bytes(parts)]
+
+    def hits(self, slots, scores) -> list[dict[str, Any]]:
+        """Hit dictionaries of a flat list of (slot, score) pairs, payloads fetched together."""
+        slots = [int(t) for t in slots]
+        pays = self.payloads_of(slots)
+        return [{"id": self.ids.get(t), "score": float(sc), "payload": p} for t, sc, p in zip(slots, scores, pays)]
 
     def search(self, queries: np.ndarray, limit: int, dfilt) -> tuple[np.ndarray, np.ndarray]:
         """(scores [nq, limit], slots [nq, limit]); -1 slots are padding."""
@@ -310,9 +384,14 @@ class _Collection:
             os.makedirs(tmp, exist_ok=True)
         self.shards._everyone(None)                               # (every rank sees the directory before writing into it)
         self.shards.save(tmp)
+        if self.partial:                                          # a rank's payload table holds the text of its own rows only: one table per rank
+            sub = os.path.join(tmp, f"tables{self.shards.rank}")
+            os.makedirs(sub, exist_ok=True)
+            self.payloads.save(sub)
         if primary:
             self.ids.save(tmp)
-            self.payloads.save(tmp)
+            if not self.partial:
+                self.payloads.save(tmp)
             self.row_shard.tofile(os.path.join(tmp, "rows.shard.i32"))
             self.row_local.tofile(os.path.join(tmp, "rows.local.i64"))
             with open(os.path.join(tmp, "collection.json"), "w") as f:
@@ -335,7 +414,7 @@ class _Collection:
         self.shards.load(directory)
         n = int(meta["slots"])
         self.ids.load(directory, n)
-        self.payloads.load(directory)
+        self.payloads.load(os.path.join(directory, f"tables{self.shards.rank}") if self.partial else directory)
         self.row_shard = np.fromfile(os.path.join(directory, "rows.shard.i32"), np.int32)
         self.row_local = np.fromfile(os.path.join(directory, "rows.local.i64"), np.int64)
         if self.payloads.n != n or sum(self.shards.rows) != n or list(self.shards.rows) != [int(v) for v in meta["shard_rows"]]:
@@ -425,13 +504,18 @@ class _RawClient:
     def _host_select(self, col: _Collection, conds) -> np.ndarray:
         """Slots whose payload meets conditions on keys the device does not code: a walk over the alive slots' columns."""
         slots = []
+        mine = set(col.shards.owned)
         for t in col.matching_slots(None):
+            if col.partial and int(col.row_shard[t]) not in mine:
+                continue                                  # (one process per shard: a row's text is with its owner, who answers for it)
             ok = True
             for key, kind, value in conds:
                 have = col.payloads.value(int(t), key)
                 ok = ok and ((isinstance(have, str) and str(value) in have) if kind == "text" else have == value)
             if ok:
                 slots.append(int(t))
+        if col.partial:
+            slots = sorted(t for part in col.shards._everyone(slots) for t in part)
         return np.asarray(slots, dtype=np.int64)
 
     async def count(self, collection_name: str, count_filter=None, exact: bool = True):
@@ -630,11 +714,14 @@ class HipVectorStore:
             raise VectorStoreError(f"Failed to get collection info for {collection}", cause=e)
 
     # ------------------------------------------------------------------ data path
-    async def upsert(self, collection: str, ids: list[str], vectors, payloads: list[dict[str, Any]]) -> None:
+    async def upsert(self, collection: str, ids: list[str], vectors, payloads: list[dict[str, Any]], *, texts=None, embed=None) -> None:
         """client.py:115-130.  Same id again replaces the point (Qdrant upsert semantics).  ``vectors``: the reference's
-        list of float lists, or -- without the list round trip -- a float32 ndarray / a CUDA tensor [n, dim]."""
+        list of float lists, or -- without the list round trip -- a float32 ndarray / a CUDA tensor [n, dim].
+        ``vectors=None`` with ``texts`` and ``embed`` (a callable ``list[str] -> [m, dim]``, e.g. ``provider.embed_texts_sync``):
+        the store routes the rows first and THIS process embeds only the texts of the shards it owns -- with one process per GPU
+        (``shards=N``, backend "dist") rank g embeds and stores exactly its share, no vector ever crosses ranks."""
         try:
-            await self._run(lambda: self._col(collection).upsert(ids, vectors, payloads))
+            await self._run(lambda: self._col(collection).upsert(ids, vectors, payloads, texts=texts, embed=embed))
             logger.debug(f"Upserted {len(ids)} vectors to {collection}")
         except Exception as e:
             raise VectorStoreError(f"Failed to upsert vectors to {collection}", cause=e)
@@ -655,8 +742,13 @@ class HipVectorStore:
         read.  ``limits``: one int for all queries, or one per query (coalesced callers keep their own prefix)."""
         per = [int(limits)] * queries.shape[0] if isinstance(limits, (int, np.integer)) else [int(v) for v in limits]
         col, scores, slots = self._search_sync(collection, queries, max(per, default=0), filters)
-        return [[col.hit(int(r), float(s)) for s, r in zip(srow[:max(lim, 0)], rrow[:max(lim, 0)]) if r >= 0]
-                for lim, srow, rrow in zip(per, scores, slots)]
+        picked = [[(int(r), float(s)) for s, r in zip(srow[:max(lim, 0)], rrow[:max(lim, 0)]) if r >= 0] for lim, srow, rrow in zip(per, scores, slots)]
+        flat = col.hits([t for one in picked for t, _ in one], [sc for one in picked for _, sc in one])      # (payloads fetched together)
+        out, at = [], 0
+        for one in picked:
+            out.append(flat[at:at + len(one)])
+            at += len(one)
+        return out
 
     async def search(self, collection: str, query_vector: list[float] | None, limit: int = 10,
                      filters: dict[str, Any] | None = None) -> list[dict[str, Any]]:
@@ -666,7 +758,8 @@ class HipVectorStore:
             if query_vector is None:
                 def fetch():
                     col = self._col(collection)
-                    return [col.hit(int(t), 0.0) for t in col.matching_slots(filters, limit=limit)]
+                    slots = col.matching_slots(filters, limit=limit)
+                    return col.hits(slots, [0.0] * len(slots))
                 results = await self._run(fetch)
             elif len(query_vector) != self._col(collection).shards.dim:   # (must not fail the pass it would have joined)
                 raise ValueError(f"query dim {len(query_vector)} != index dim {self._col(collection).shards.dim}")
@@ -762,7 +855,8 @@ class HipVectorStore:
                     c = int(out.count[qi])
                     pos = out.index[qi, :c] if c >= 0 else np.flatnonzero(slots[qi] >= 0)
                     wanted.update(int(t) for t in slots[qi, pos] if t >= 0)
-                return RerankHits({t: (col.ids.get(t), col.payloads.get(t)) for t in wanted}, col._degrees), out, slots, s.cpu().numpy()
+                wanted = sorted(wanted)
+                return RerankHits({t: (col.ids.get(t), p) for t, p in zip(wanted, col.payloads_of(wanted))}, col._degrees), out, slots, s.cpu().numpy()
             return await self._run(work)
         except Exception as e:
             raise VectorStoreError(f"Failed to search {collection}", cause=e)
@@ -788,6 +882,37 @@ class HipVectorStore:
         except Exception as e:
             logger.warning(f"Error checking file update status: {e}")
             return True
+
+    async def files_need_update(self, collection: str, files: list[tuple[str, str]]) -> list[bool]:
+        """:meth:`file_needs_update` for many ``(file_path, content_hash)`` pairs in ONE job (a batched indexer asks once for a
+        whole project instead of once per file); True on a miss, on a different stored hash, and for every file on ANY error."""
+        try:
+            def work():
+                col = self._col(collection)
+                out = []
+                for file_path, content_hash in files:
+                    slots = col.matching_slots({"file_path": file_path}, limit=1)
+                    out.append(True if not len(slots) else col.payloads.value(int(slots[0]), "content_hash") != content_hash)
+                return out
+            return [bool(v) for v in await self._run(work)]
+        except Exception as e:
+            logger.warning(f"Error checking file update status: {e}")
+            return [True] * len(files)
+
+    async def delete_files(self, collection: str, file_paths: list[str]) -> None:
+        """``delete(collection, {"file_path": p})`` for many files in ONE job (a path the collection has never stored costs a
+        dictionary look-up and no device call); the collection compacts at most once, at the end."""
+        try:
+            def work():
+                col = self._col(collection)
+                for p in file_paths:
+                    dfilt = col.device_filters({"file_path": p})
+                    if dfilt:
+                        col.shards.tombstone_filter(dfilt)
+                col.maybe_compact()
+            await self._run(work)
+        except Exception as e:
+            raise VectorStoreError(f"Failed to delete from {collection}", cause=e)
 
     async def compact(self, collection: str | None = None) -> int:
         """Reclaim the rows of deleted points (``crh_index_compact`` + the host tables): what Qdrant's optimizer does in the

@@ -34,8 +34,18 @@ def lib() -> C.CDLL:
         L.crt_token_to_id.restype = C.c_int
         L.crt_encode_batch.argtypes = [C.c_void_p, C.c_int64, pp, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.crt_encode_batch.restype = C.c_int64
+        L.crt_count_wordish_ascii.argtypes = [C.c_char_p, C.c_int64]
+        L.crt_count_wordish_ascii.restype = C.c_int64
         _lib = L
     return _lib
+
+
+def count_wordish_ascii(text: str) -> int:
+    """Matches of ``\\w+|[^\\w\\s]`` in an ASCII text, -1 when the text is not ASCII (``crt_count_wordish_ascii``)."""
+    if not text.isascii():
+        return -1
+    b = text.encode("ascii")
+    return int(lib().crt_count_wordish_ascii(b, len(b)))
 
 
 def _strs(items):

@@ -28,6 +28,8 @@ def test_self_launch_prints_one_json_line_with_all_ranks(n, scaling):
     assert rec["value"] is None and rec["backend"] == "gloo"            # a rehearsal never looks like a measurement
     assert len(rec["per_rank_step_ms"]) == n and rec["scaling"] == scaling
     assert rec["rows_per_gpu"] == (4096 // n if scaling == "strong" else 4096)
+    assert rec["legs_rehearsed"].get("c2") is True                      # default legs at N > 1 now include c2 (per-rank embed -> local shard -> sharded top-k)
+    assert len(rec["per_rank_nomination"]) == n and len(rec["per_rank_fallback_used"]) == n
 
 
 def test_eight_ranks_strong_scaling_with_the_config5_and_embed_collectives():
@@ -40,6 +42,9 @@ def test_eight_ranks_strong_scaling_with_the_config5_and_embed_collectives():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["collective_ranks"] == 8 and rec["exchange_layout_ok"] is True
     assert rec["legs_rehearsed"] == {"config5": True, "embed": True}
+    # the first real SCALE record must show at a glance whether every rank took the int8 pass: [mode, fallback_used] of every
+    # rank travel in one all-gather (here the rehearsal's stand-ins, -1 - rank and rank, in rank order)
+    assert rec["per_rank_nomination"] == [-1 - r for r in range(8)] and rec["per_rank_fallback_used"] == list(range(8))
     assert rec["rows_per_gpu"] == 10000 and rec["scaling"] == "strong" and len(rec["per_rank_step_ms"]) == 8
     assert [d["rank"] for d in rec["per_rank_device"]] == list(range(8)) and sorted(d["local_rank"] for d in rec["per_rank_device"]) == list(range(8))
 

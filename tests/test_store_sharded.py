@@ -172,3 +172,183 @@ def test_store_on_one_process_per_shard_gloo_world_2(tmp_path):
         port = so.getsockname()[1]
     mp.spawn(_dist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert {"ok0", "ok1"} <= set(os.listdir(tmp_path))
+
+
+# ---------------------------------------------------------------------------------------------- sharded ingest (round 4)
+
+def _fake_embed_vectors(texts):
+    """Deterministic stand-in for the encoder: a text's vector depends on the text alone."""
+    import zlib
+    out = np.empty((len(texts), 768), np.float32)
+    for i, t in enumerate(texts):
+        out[i] = np.random.default_rng(zlib.crc32(t.encode())).standard_normal(768)
+    return out
+
+
+async def _ingest_and_query(s, log, counter):
+    n = 700
+    texts = [f"def fn_{i}():\n    return {i} * {i % 7}\n" for i in range(n)]
+    ids = [str(uuid.UUID(int=i + 1)) for i in range(n)]
+    pay = [{"file_path": f"/p/f{i % 20}.py", "entity_type": "function", "entity_name": f"fn_{i}", "language": "python", "start_line": i,
+            "end_line": i + 2, "content": texts[i], "graph_node_id": None if i % 2 else f"m.fn_{i}", "content_hash": f"h{i % 20}", "project_name": "p"}
+           for i in range(n)]
+
+    def embed(chunk):
+        counter.append(len(chunk))
+        return _fake_embed_vectors(chunk)
+    async with s:
+        await s.create_collections()
+        for a in range(0, n, 175):
+            await s.upsert("code_chunks", ids[a:a + 175], None, pay[a:a + 175], texts=texts[a:a + 175], embed=embed)
+        log.append((await s.get_collection_info("code_chunks")).points_count)
+        qv = _fake_embed_vectors([texts[3], texts[333], "something else entirely"])
+        for q in qv:
+            log.append([(h["id"], h["score"], h["payload"]) for h in await s.search("code_chunks", q.tolist(), limit=12)])
+        log.append([[(h["id"], h["payload"]["content"]) for h in hs] for hs in await s.search_batch("code_chunks", qv, limit=5, filters={"file_path": "/p/f3.py"})])
+        log.append([(h["id"], h["payload"]) for h in await s.search("code_chunks", None, limit=6, filters={"file_path": "/p/f7.py"})])
+        # the reference's re-index of a file: delete by path, embed and upsert again (fresh ids)
+        await s.delete("code_chunks", {"file_path": "/p/f3.py"})
+        rows = [i for i in range(n) if i % 20 == 3]
+        await s.upsert("code_chunks", [str(uuid.UUID(int=5000 + i)) for i in rows], None, [dict(pay[i], content_hash="new") for i in rows],
+                       texts=[texts[i] + "# v2\n" for i in rows], embed=embed)
+        log.append([(h["id"], h["score"], h["payload"]) for h in await s.search("code_chunks", _fake_embed_vectors([texts[3] + "# v2\n"])[0].tolist(), limit=4)])
+        from types import SimpleNamespace as M
+        log.append((await s.client.count("code_chunks", count_filter=M(must=[M(key="content", match=M(text="return 33 "))]))).count)
+        import tempfile
+        with tempfile.TemporaryDirectory() as snap:
+            snap = getattr(s, "_test_snap", None) or snap
+            await s.save(snap)
+            await s.load(snap)
+        log.append([(h["id"], h["score"], h["payload"]) for h in await s.search("code_chunks", qv[1].tolist(), limit=8)])
+        info = await s.get_collection_info("code_chunks")
+        return info, len(s._collections["code_chunks"].payloads.cols["content"].blob)      # bytes of payload text this process holds
+
+
+def _ingest_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _patch_fake()
+    from coderag_amd import shards as shards_mod
+    orig = shards_mod.ShardSet.__init__
+
+    def small_blocks(self, *a, **kw):
+        kw["block"] = 32
+        orig(self, *a, **kw)
+    shards_mod.ShardSet.__init__ = small_blocks
+    s = _store(world)
+    s._test_snap = os.path.join(out_dir, "snap")
+    log, seen = [], []
+    info, text_bytes = asyncio.run(_ingest_and_query(s, log, seen))
+    shards_mod.ShardSet.__init__ = orig
+    # this rank's encoder saw exactly the rows routed to its shard -- nothing more, and no rank saw everything
+    assert sum(seen) == info.config["shard_rows"][rank], (rank, sum(seen), info.config["shard_rows"])
+    assert 0 < sum(seen) < sum(info.config["shard_rows"])
+    ref, ref_seen = [], []
+    _, ref_text_bytes = asyncio.run(_ingest_and_query(_store(1), ref, ref_seen))
+    assert log == ref, f"rank {rank}: sharded ingest and the unsharded store disagree"
+    assert sum(ref_seen) == sum(info.config["shard_rows"])          # the unsharded store embedded every text in one place
+    # this rank's payload table holds the text of its own rows only
+    assert 0 < text_bytes < 0.7 * ref_text_bytes, (text_bytes, ref_text_bytes)
+    open(os.path.join(out_dir, f"ingest_ok{rank}"), "w").write(f"{sum(seen)} {text_bytes} {ref_text_bytes}")
+    dist.destroy_process_group()
+
+
+def test_sharded_ingest_every_rank_embeds_and_stores_its_own_share_gloo_world_2(tmp_path):
+    """SURVEY 8(e), embed row / round-3 review: rank g embeds texts[shard == g] and appends them to ITS shard, no exchange of
+    vectors; payload text lives with the owning rank only and hits fetch it in one byte exchange (tensor collectives); results
+    equal the unsharded store, snapshot included (embeddings/indexer.py:46-94 with the rows sharded across processes)."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_ingest_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = sorted(os.listdir(tmp_path))
+    assert {"ingest_ok0", "ingest_ok1"} <= set(got)
+    rec = [[int(v) for v in open(os.path.join(tmp_path, f"ingest_ok{r}")).read().split()] for r in range(2)]
+    shares = [r[0] for r in rec]
+    assert sum(shares) == 700 + 35 and min(shares) > 250           # 700 chunks + the 35 of the re-indexed file, split by blocks of 32
+    assert rec[0][1] + rec[1][1] == rec[0][2]                      # the ranks' payload text adds up to the unsharded store's: nothing is held twice
+
+
+def test_lazy_upsert_on_in_process_shards_and_payload_text_placement(fake):
+    """`vectors=None` on the local back-end embeds every text once (all shards are here) and behaves like the eager form; a
+    failed embed leaves tables, routing and shards untouched."""
+    from coderag_amd import store as store_mod
+    calls = []
+
+    def embed(chunk):
+        calls.append(len(chunk))
+        return _fake_embed_vectors(chunk)
+
+    async def go():
+        async with _store(3) as s:
+            await s.create_collections()
+            texts = [f"t{i}" for i in range(300)]
+            await s.upsert("code_chunks", [f"id{i}" for i in range(300)], None, [{"file_path": f"f{i % 4}.py", "content": t} for i, t in enumerate(texts)],
+                           texts=texts, embed=embed)
+            assert sum(calls) == 300
+            hit = (await s.search("code_chunks", _fake_embed_vectors(["t42"])[0].tolist(), limit=1))[0]
+            assert hit["id"] == "id42" and hit["payload"] == {"file_path": "f2.py", "content": "t42"}
+            before = (await s.get_collection_info("code_chunks")).config
+
+            def broken(chunk):
+                raise RuntimeError("encoder down")
+            with pytest.raises(store_mod.VectorStoreError):
+                await s.upsert("code_chunks", ["x1", "x2"], None, [{"file_path": "g.py"}] * 2, texts=["a", "b"], embed=broken)
+            after = (await s.get_collection_info("code_chunks")).config
+            assert after["shard_rows"] == before["shard_rows"] and (await s.get_collection_info("code_chunks")).points_count == 300
+            await s.upsert("code_chunks", ["x1"], None, [{"file_path": "g.py", "content": "late"}], texts=["late"], embed=embed)   # the store still works
+            assert (await s.search("code_chunks", _fake_embed_vectors(["late"])[0].tolist(), limit=1))[0]["id"] == "x1"
+    asyncio.run(go())
+
+
+def test_an_append_that_fails_half_way_leaves_the_collection_consistent(fake, monkeypatch):
+    """Round-3 advisor finding: ShardSet.append commits shard by shard; when a later shard refuses (out of memory, capacity), the
+    earlier shards already hold rows that have no slot.  Now: capacity is reserved on every shard first; rows that did land are
+    tombstoned and the slot maps step over them, so later appends still map local rows to the right slots."""
+    from coderag_amd import shards as shards_mod
+    from tests.fake_index import FakeIndex
+    orig = shards_mod.ShardSet.__init__
+
+    def small_blocks(self, *a, **kw):
+        kw["block"] = 16
+        orig(self, *a, **kw)
+    monkeypatch.setattr(shards_mod.ShardSet, "__init__", small_blocks)
+    rng = np.random.default_rng(21)
+    vecs = rng.standard_normal((300, 768)).astype(np.float32)
+
+    async def go():
+        async with _store(3) as s:
+            await s.create_collections()
+            await s.upsert("code_chunks", [f"a{i}" for i in range(100)], vecs[:100], [{"file_path": "a.py", "content": f"a{i}"} for i in range(100)])
+            col = s._collections["code_chunks"]
+            victim = col.shards.index[1]
+            real, state = FakeIndex.append, {"armed": True}
+
+            def flaky(self, *a, **kw):
+                if self is victim and state["armed"]:
+                    state["armed"] = False
+                    raise MemoryError("shard 1 is full")
+                return real(self, *a, **kw)
+            monkeypatch.setattr(FakeIndex, "append", flaky)
+            from coderag_amd.errors import VectorStoreError
+            with pytest.raises(VectorStoreError):
+                await s.upsert("code_chunks", [f"b{i}" for i in range(100)], vecs[100:200], [{"file_path": "b.py", "content": f"b{i}"} for i in range(100)])
+            info = await s.get_collection_info("code_chunks")
+            assert info.points_count == 100                         # nothing of the failed call is visible
+            assert info.config["rows_appended"] > 100               # ... although shard 0 took (and lost) its share
+            # the store goes on: later rows land behind the orphans and are found under their own ids
+            await s.upsert("code_chunks", [f"c{i}" for i in range(100)], vecs[200:300], [{"file_path": "c.py", "content": f"c{i}"} for i in range(100)])
+            for i in (0, 37, 99):
+                top = (await s.search("code_chunks", vecs[200 + i].tolist(), limit=1))[0]
+                assert top["id"] == f"c{i}" and top["payload"]["content"] == f"c{i}"
+                top = (await s.search("code_chunks", vecs[i].tolist(), limit=1))[0]
+                assert top["id"] == f"a{i}"
+            assert not any(h["id"].startswith("b") for h in await s.search("code_chunks", vecs[150].tolist(), limit=20))
+            assert (await s.get_collection_info("code_chunks")).points_count == 200
+            await s.compact("code_chunks")                          # the orphans go with the next compaction
+            info = await s.get_collection_info("code_chunks")
+            assert info.config["rows_appended"] == info.points_count == 200
+            assert (await s.search("code_chunks", vecs[250].tolist(), limit=1))[0]["id"] == "c50"
+    asyncio.run(go())
