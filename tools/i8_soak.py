@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the int8 nomination against the three-launch bf16 scan on the SAME index (no oracle: the two forms share only the
 canonical selection, so a row the intervals wrongly excluded shows as a difference): many batches of varied queries -- Gaussian,
-sparse, stored rows, scaled sums of rows, near-duplicates --, varied k, filters and tombstones, three widths, both stores.
+sparse, stored rows, scaled sums of rows, near-duplicates, saturated sign patterns against saturated rows --, varied k, filters and tombstones, three widths, both stores.
 python tools/i8_soak.py [batches per configuration]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +22,16 @@ for dim, n in ((768, 300_000), (384, 200_000), (1536, 120_000)):
         x[sp, rng.integers(0, dim, len(sp))] += 60.0
         x[rng.choice(n, 2000, replace=False)] = x[rng.choice(n, 2000, replace=False)]
         x[rng.choice(n, 500, replace=False)] *= 1e-12
+        # saturated rows: every element at +-c (their int8 images are all +-127: the integer dots reach 127 * 127 * dim, beyond
+        # 2^24 at dim 1536 -- the rounding allowance of the intervals, crh_i8.hpp kDotRound), a few signs flipped per row
+        pool = rng.choice([-1.0, 1.0], (64, dim)).astype(np.float32)
+        sat = rng.choice(n, n // 20, replace=False)
+        rows_ = pool[rng.integers(0, 64, len(sat))] * rng.choice([1.0, -1.0, 0.2], (len(sat), 1)).astype(np.float32)
+        for i in range(len(sat)):
+            f = int(rng.integers(0, 30))
+            if f:
+                rows_[i, rng.choice(dim, f, replace=False)] *= -1.0
+        x[sat] = rows_
         codes = rng.integers(0, 4, (n, 1)).astype(np.int32)
         idx = ffi.Index(dim, dtype, capacity_rows=n, n_code_cols=1)
         idx.append(x, codes)
@@ -29,8 +39,10 @@ for dim, n in ((768, 300_000), (384, 200_000), (1536, 120_000)):
         nqmax = 32 if dim == 1536 else 64
         for b in range(nb):
             nq = int(rng.integers(1, nqmax + 1))
-            kind = b % 5
-            if kind == 0:
+            kind = b % 6
+            if kind == 5:        # saturated queries: a sign pattern of the pool (the saturated rows' near neighbours), constant magnitude
+                q = pool[rng.integers(0, 64, nq)] * np.float32(0.5)
+            elif kind == 0:
                 q = rng.standard_normal((nq, dim), dtype=np.float32)
             elif kind == 1:
                 q = np.zeros((nq, dim), np.float32)
