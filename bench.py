@@ -1428,12 +1428,22 @@ def index_e2e_leg(np, torch, local_rank, box, n_files=600):
             again = await (indexer.index_files_batched if batched else indexer.index_files)(files[:50], project_name="proj")      # unchanged: skipped
             return n, dt, (top["payload"]["entity_name"], top["payload"]["file_path"]), again, (await store.get_collection_info("code_chunks")).points_count
     asyncio.run(embedder.embed_batch(["warm up"] * 64))
+    # the bound of this leg: the encoder alone on the very texts the files chunk into (they are longer than the embed leg's mix)
+    all_texts = [c.content for f in files for c in CodeChunker(max_tokens=1000, overlap_tokens=200).chunk_file(f, project_name="proj")]
+    asyncio.run(embedder.embed_array(all_texts[:4096]))
+    t0 = time.perf_counter()
+    asyncio.run(embedder.embed_array(all_texts))
+    t_enc = time.perf_counter() - t0
+    mean_tok = float(np.minimum(provider._load().tok.encode_bodies(all_texts[:4000], 508)[1], 508).mean() + 4)
     n_b, t_b, top_b, again_b, count_b = asyncio.run(one(True))
     n_s, t_s, top_s, again_s, count_s = asyncio.run(one(False))
     same = bool(n_b == n_s == count_b == count_s and top_b == top_s == ("mod7.fn_7_3", "/proj/mod7.py") and again_b == again_s == 0)
-    log(f"index_e2e: batched {n_b / t_b:.0f} chunks/s, sequential (the reference's flow) {n_s / t_s:.0f} chunks/s, same outcome {same}")
+    log(f"index_e2e: batched {n_b / t_b:.0f} chunks/s (the encoder alone on these texts, mean {mean_tok:.0f} tokens: {len(all_texts) / t_enc:.0f}), "
+        f"sequential (the reference's flow) {n_s / t_s:.0f} chunks/s, same outcome {same}")
     return {"metric": "chunks indexed/s through VectorIndexer -> CodeChunker -> Embedder -> provider -> HipVectorStore.upsert", "value": n_b / t_b,
-            "unit": "chunks/s", "files": n_files, "chunks": n_b, "seconds": t_b,
+            "unit": "chunks/s", "files": n_files, "chunks": n_b, "seconds": t_b, "mean_tokens": mean_tok,
+            "encoder_alone": {"value": len(all_texts) / t_enc, "seconds": t_enc, "what": "ONE embed_array call over the same chunk texts (tokenizer + packed forward + copy back), "
+                              "nothing else: the bound of this leg", "leg_over_encoder_alone": (n_b / t_b) / (len(all_texts) / t_enc)},
             "flow": "VectorIndexer.index_files_batched: one update check, one delete job, all files chunked, one coalesced embedding submission (float32 array), one upsert",
             "sequential": {"value": n_s / t_s, "seconds": t_s, "flow": "VectorIndexer.index_files (indexer.py:96-119): per file update check, delete, chunk, embed_with_progress, upsert"},
             "data": "600 synthetic parsed files of 8-40 entities cut from this repo's Python sources; byte-level BPE vocabulary (8000) trained on them; seeded 12-layer weights",

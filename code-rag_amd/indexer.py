@@ -154,7 +154,7 @@ class SummarySearchResult:
 
 
 class VectorIndexer:
-    GROUP = 4096       # chunks per pipelined group of index_files_batched (one length-bucketed submission of ~1.5M tokens)
+    GROUP, GROUP_FIRST = 8192, 1024      # chunks per pipelined group of index_files_batched: the first group / the largest
 
     def __init__(self, qdrant, embedder, chunker=None):
         self.qdrant = qdrant
@@ -247,14 +247,21 @@ class VectorIndexer:
             # Chunking is host work (the token counter), embedding is device work driven from the provider's thread, the upsert
             # runs on the store's: groups of ~GROUP chunks go down the three stages one behind the other, so the encoder is fed
             # while the next group is being cut (14 k chunks: chunking 0.2 s + tables 0.1 s beside 1.0 s of encoder).
-            total, group = 0, []
+            # (the chunking loop holds the interpreter lock in 5 ms slices by default; the provider's thread needs it for a few
+            # microseconds between kernel launches and would wait out every slice: hand it over a hundred times more often)
+            import sys
+            switch = sys.getswitchinterval()
+            sys.setswitchinterval(min(switch, 5e-5))
+            total, group, want = 0, [], self.GROUP_FIRST
             for f in todo:
                 group.extend(self.chunker.chunk_file(f, project_name=project_name))
-                if len(group) >= self.GROUP:
+                if len(group) >= want:
                     if in_flight is not None:
                         await in_flight
                     in_flight, total, group = asyncio.ensure_future(embed_and_store(group)), total + len(group), []
+                    want = min(self.GROUP, want * 4)            # a small first group (the encoder starts early), then large ones (fewer, fuller submissions)
                     await asyncio.sleep(0)                      # (let the new task reach its first await: the executor hand-over)
+            sys.setswitchinterval(switch)
             if in_flight is not None:
                 await in_flight
             if group:
@@ -267,6 +274,9 @@ class VectorIndexer:
             return total
         except Exception as e:  # noqa: BLE001
             logger.error(f"Batched indexing failed ({e!r}); indexing the files one by one")
+            import sys
+            if sys.getswitchinterval() < 1e-3:
+                sys.setswitchinterval(0.005)
             if in_flight is not None and not in_flight.done():      # (a group still on its way must land, or fail, before its files are looked at again)
                 try:
                     await in_flight
