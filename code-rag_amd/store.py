@@ -600,7 +600,9 @@ class HipVectorStore:
         # waits that long before each pass; < 0 (or CODERAG_HIP_SEARCH_WINDOW_MS=-1) turns coalescing off.
         if search_window_ms is None:
             search_window_ms = float(os.environ.get("CODERAG_HIP_SEARCH_WINDOW_MS", "0"))
-        self._search_coalesce = search_window_ms >= 0
+        # (one process per shard: every search ends in collectives, so all ranks must cut their calls into the SAME passes; how
+        # many concurrent calls a pass picks up depends on each rank's own timing -- there, every call is its own pass)
+        self._search_coalesce = search_window_ms >= 0 and self._shard_backend != "dist"
         self._search_window_s = max(0.0, search_window_ms) / 1e3
         self._search_pending: dict[tuple, list] = {}
         self._search_drainers: dict[tuple, asyncio.Task] = {}

@@ -145,3 +145,38 @@ def test_reindexing_the_same_files_five_times_does_not_grow_the_index(gpu):
                 n = np.fromfile(os.path.join(d, "code_chunks", "alive.u32"), np.uint32)
                 assert int(sum(bin(int(w)).count("1") for w in n)) == 200 and len(n) == 7       # 200 rows = 7 tiles, every stored row alive
     asyncio.run(compacted())
+
+
+def test_batched_indexing_and_lazy_upsert_on_the_gpu(gpu):
+    """`VectorIndexer.index_files_batched` (one pass: chunk -> ONE coalesced embedding submission as an array -> one upsert) and
+    the store-side form (`embed_in_store=True`: `upsert(vectors=None, texts=..., embed=provider.embed_texts_sync)`, here on three
+    in-process shards) leave the store exactly as the reference's per-file flow does: same chunks and payloads, the same hits
+    with the same f32 scores for a query (embeddings do not depend on the batch they travelled in)."""
+    import coderag_amd  # noqa: F401
+    from coderag_amd.embedder import Embedder
+    from coderag_amd.indexer import CodeChunker, VectorIndexer
+    from coderag_amd.providers import HipUniXcoderProvider, ProviderConfig
+    from coderag_amd.store import HipVectorStore
+    from coderag_amd.vector_search import VectorSearcher
+    provider = HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model="synthetic", extra={"synthetic_weights": 5, "num_layers": 2}))
+    embedder = Embedder(provider_instance=provider)
+    files = [_parsed_file(f"/proj/mod{f}.py", [(f"fn_{f}_{i}", f"def fn_{f}_{i}(x):\n    y = x * {i} + {f}\n    return helper_{i % 3}(y)\n" * (1 + i % 4))
+                                                for i in range(5 + f % 3)]) for f in range(9)]
+    query = files[4].all_entities[2].code
+
+    async def run(mode, shards):
+        async with HipVectorStore(dim=embedder.embedding_dim, dtype="f32", initial_capacity=64, shards=shards) as store:
+            await store.create_collections()
+            indexer = VectorIndexer(store, embedder, CodeChunker(max_tokens=1000, overlap_tokens=200))
+            if mode == "sequential":
+                n = await indexer.index_files(files, project_name="proj")
+            else:
+                n = await indexer.index_files_batched(files, project_name="proj", embed_in_store=(mode == "in_store"))
+            assert await indexer.index_files_batched(files, project_name="proj") == 0                     # unchanged: skipped
+            hits = await VectorSearcher(store, embedder).search_code(query, limit=8, project_name="proj")
+            return n, [(h["entity_name"], h["file_path"], h["start_line"], h["content"], np.float32(h["score"]).tobytes()) for h in hits]
+    seq = asyncio.run(run("sequential", 1))
+    bat = asyncio.run(run("batched", 1))
+    ins = asyncio.run(run("in_store", 3))
+    assert seq[0] == bat[0] == ins[0] == sum(5 + f % 3 for f in range(9))
+    assert seq[1] == bat[1] == ins[1] and seq[1][0][0] == "mod4.fn_4_2"
