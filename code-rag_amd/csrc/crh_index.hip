@@ -544,7 +544,10 @@ int finish_pending(crh_index *h, hipStream_t st)
     CRH_HIP(hipStreamSynchronize(st));
     const int used = std::max(1, std::min(h->next_slot, kStatusSlots));   // slots are handed out in order from 0
     std::vector<SearchStatus> host((size_t)used);
-    CRH_HIP(hipMemcpy(host.data(), h->status, sizeof(SearchStatus) * (size_t)used, hipMemcpyDeviceToHost));
+    // (copies of the search path go through `st`, not through hipMemcpy: that one runs on the NULL stream and would wait for everything
+    // another thread has queued there -- an encoder forward under way on torch's default stream held every answer back ~13 ms)
+    CRH_HIP(hipMemcpyAsync(host.data(), h->status, sizeof(SearchStatus) * (size_t)used, hipMemcpyDeviceToHost, st));
+    CRH_HIP(hipStreamSynchronize(st));
     std::vector<Pending> todo;
     todo.swap(h->pending);
     h->next_slot = 0;
@@ -614,8 +617,8 @@ int finish_pending(crh_index *h, hipStream_t st)
             const int rc = enqueue_batch(h, w, p.q_dev, p.nq, p.k, mask, p.row_base, p.out_s, p.out_r, 0, st, &path);
             h->i8_suppress = false;
             CRH_TRY(rc);
+            CRH_HIP(hipMemcpyAsync(&s, h->status, sizeof(SearchStatus), hipMemcpyDeviceToHost, st));
             CRH_HIP(hipStreamSynchronize(st));
-            CRH_HIP(hipMemcpy(&s, h->status, sizeof(SearchStatus), hipMemcpyDeviceToHost));
         }
         h->stats.candidates += (int64_t)s.candidates;
         h->stats.max_query_cands = std::max<int64_t>(h->stats.max_query_cands, s.max_qcount);
@@ -1280,8 +1283,9 @@ int crh_search(crh_index *h, int nq, const float *queries, int queries_on_device
     if (!out_on_device || !queries_on_device) {
         CRH_TRY(finish_pending(h, st));
         if (!out_on_device) {
-            CRH_HIP(hipMemcpy(out_scores, h->stage_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-            CRH_HIP(hipMemcpy(out_rows, h->stage_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+            CRH_HIP(hipMemcpyAsync(out_scores, h->stage_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+            CRH_HIP(hipMemcpyAsync(out_rows, h->stage_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+            CRH_HIP(hipStreamSynchronize(st));
         }
     }
     return CRH_OK;

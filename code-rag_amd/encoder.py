@@ -17,6 +17,7 @@ from __future__ import annotations
 import json
 import math
 import os
+import time
 import re
 import threading
 import zlib
@@ -25,6 +26,11 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import ffi
+
+
+def _yield_gil() -> None:
+    """Let a thread that is waiting for the interpreter lock have it now (``time.sleep(0)`` releases the lock and yields the CPU)."""
+    time.sleep(0)
 
 
 @dataclass(frozen=True)
@@ -236,6 +242,10 @@ class HipUniXcoder:
         gemm, gemm_ln = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln
         check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, T, Lmax, H, st))
         for ly in self._layer_ptrs:
+            # (a launch loop re-takes the interpreter lock microseconds after every ctypes call: a thread that waits for it -- the
+            # store's worker answering a query beside this indexing run -- would otherwise get it only at the 5 ms switch
+            # interval, per hop; yielding once per layer costs a microsecond and lets it in within a layer's ~1 ms)
+            _yield_gil()
             check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
             check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, T, Lmax, cfg.num_heads, st))
             check(gemm_ln(pctx, ly["o_w"], ly["o_b"], px, ly["ln1_g"], ly["ln1_b"], eps, px1, T, H, H, st))

@@ -34,6 +34,7 @@ class HotPathSettings:
     hip_shard_backend: str
     hip_compact_dead_fraction: float
     hip_compact_min_dead: int
+    hip_store_stream: str
 
 
 def get_settings() -> HotPathSettings:
@@ -54,4 +55,5 @@ def get_settings() -> HotPathSettings:
         hip_shard_backend=os.environ.get("CODERAG_HIP_SHARD_BACKEND", "auto").lower(),     # local | dist | auto
         hip_compact_dead_fraction=float(os.environ.get("CODERAG_HIP_COMPACT_DEAD_FRACTION", "0.25") or 0.25),
         hip_compact_min_dead=_int("CODERAG_HIP_COMPACT_MIN_DEAD", 1024),
+        hip_store_stream=os.environ.get("CODERAG_HIP_STORE_STREAM", "priority").lower(),    # priority | default (store.py: the stream its device work runs on)
     )

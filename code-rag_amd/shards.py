@@ -60,6 +60,7 @@ class ShardSet:
         else:
             raise ValueError(f"unknown shard backend {backend!r} (use 'local' or 'dist')")
         self.index = {s: make_index(s) for s in self.owned}
+        self.stream = 0                           # raw hipStream_t of the stream searches run on (0: the default stream); the store sets it
         self.rows = [0] * self.ns                 # rows appended to every shard so far (replicated bookkeeping: same on every rank)
         self._next_block = 0
         first = self.index[self.owned[0]]
@@ -218,7 +219,7 @@ class ShardSet:
     def search(self, queries: np.ndarray, k: int, dfilt) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Exact top-k over all shards: (scores [nq, k], shard [nq, k], local row [nq, k]); -1 rows are padding."""
         if self.ns == 1:
-            s, r = self.index[0].search(queries, k, filters=dfilt)
+            s, r = self.index[0].search(queries, k, filters=dfilt, **({"stream": self.stream} if self.stream else {}))
             return s, np.zeros(r.shape, np.int32), r
         if self._merge_host is not None:            # injected host-side index + merge (CPU test tier)
             scores, rows = self._search_host(queries, k, dfilt)

@@ -273,6 +273,8 @@ class _Collection:
                     _, local = self.shards.append(per_shard, codes, preprocessed, shard=shard)
             elif on_dev:
                 import torch
+                # (the caller's tensor comes from the device's default stream -- the encoder's --, this job may run on the store's own)
+                torch.cuda.current_stream(vecs.device).wait_stream(torch.cuda.default_stream(vecs.device))
                 vecs = vecs.contiguous() if vecs.dtype == torch.float32 else vecs.float().contiguous()
                 _, local = self.shards.append(vecs, codes, preprocessed, stream=ffi.current_stream(vecs.device), shard=shard)
                 torch.cuda.current_stream(vecs.device).synchronize()      # the caller may free / reuse its tensor right away
@@ -556,7 +558,7 @@ class HipVectorStore:
                  device: int | None = None, dim: int | None = None, dtype: str | None = None,
                  initial_capacity: int | None = None, search_window_ms: float | None = None, shards: int | None = None,
                  shard_backend: str | None = None, process_group=None, compact_dead_fraction: float | None = None,
-                 compact_min_dead: int | None = None, _merge_fn=None):
+                 compact_min_dead: int | None = None, stream: str | None = None, _merge_fn=None):
         s = get_settings()
         self._host, self._port, self._grpc_port = host, port, grpc_port
         self._device = s.hip_device if device is None else device
@@ -590,6 +592,15 @@ class HipVectorStore:
         self._shard_backend, self._group, self._merge_fn = shard_backend, process_group, _merge_fn
         self._compact = (s.hip_compact_dead_fraction if compact_dead_fraction is None else compact_dead_fraction,
                          s.hip_compact_min_dead if compact_min_dead is None else compact_min_dead)
+        # The stream the store's device work runs on.  "priority" (default): its own HIGH-PRIORITY stream -- the reference's query
+        # path runs beside its indexing path in one process (providers/unixcoder_provider.py:260: the encoder on a worker thread),
+        # and on the default stream a search queues behind every launch of a forward that is under way (13 ms for a 65 k-token
+        # batch; on an equal-priority side stream the device was still seen to leave it there); with priority its kernels get
+        # the CUs at the forward's next kernel boundary (~1 ms).  "default": torch's default stream, as in rounds 1-3.  Every
+        # job of the store completes on the host before the next starts, so mutations (host-synchronous in the library) and
+        # searches stay ordered whichever stream each used.
+        self._stream_mode = (stream or s.hip_store_stream).lower()
+        self._stream = None                        # torch.cuda.Stream, created by connect()
         self._collections: dict[str, _Collection] = {}
         self._client: _RawClient | None = None
         self._executor: ThreadPoolExecutor | None = None
@@ -618,7 +629,14 @@ class HipVectorStore:
         def guarded():
             with self._lock:
                 ffi.use_device(self._device)      # the worker thread starts on device 0 whatever CODERAG_HIP_DEVICE says
-                return fn(*args)
+                if self._stream is None:
+                    return fn(*args)
+                import torch
+                with torch.cuda.stream(self._stream):      # torch-side work and ffi.current_stream() of the job resolve to the store's stream
+                    try:
+                        return fn(*args)
+                    finally:
+                        self._stream.synchronize()           # (a job is complete when it returns: the next one may use another stream)
         return await loop.run_in_executor(self._executor, guarded)
 
     def _col(self, collection: str) -> _Collection:
@@ -638,6 +656,13 @@ class HipVectorStore:
             info = ffi.device_info(self._device)
             self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="hip-store")
             self._client = _RawClient(self)
+            if self._stream_mode == "priority":
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        self._stream = torch.cuda.Stream(device=self._device, priority=-1)
+                except ImportError:
+                    self._stream = None
             logger.info("Connected to HIP vector store on device %d (%s, %s)", self._device, info["name"], info["arch"])
         except Exception as e:
             self._client = None
@@ -654,6 +679,7 @@ class HipVectorStore:
         finally:
             self._collections = {}
             self._client = None
+            self._stream = None
             if self._executor:
                 self._executor.shutdown(wait=True)
                 self._executor = None
@@ -685,6 +711,7 @@ class HipVectorStore:
                                                               nshards=self._shards, backend=self._shard_backend, group=self._group,
                                                               merge_fn=self._merge_fn, compact_dead_fraction=self._compact[0],
                                                               compact_min_dead=self._compact[1])
+                        self._collections[name].shards.stream = int(self._stream.cuda_stream) if self._stream is not None else 0
                         logger.info(f"Created collection: {name}")
             await self._run(work)
         except Exception as e:

@@ -111,3 +111,54 @@ def test_sharded_device_rerank_equals_the_host_ranker(gpu):
         ranked = asyncio.run(go())
         out[ns] = [[(r.file_path, r.entity_name, r.start_line, r.final_score, r.source, tuple(sorted(r.signal_scores.items()))) for r in per] for per in ranked]
     assert out[1] == out[3] and all(len(per) > 0 for per in out[1])
+
+
+def test_searches_beside_an_indexing_run_use_the_stores_own_priority_stream(gpu):
+    """The reference serves queries while it indexes (one process: the encoder on the provider's worker thread,
+    providers/unixcoder_provider.py:260; the store behind its own).  With both on the device's default stream a search queues
+    behind every launch of the forward that is under way; the store therefore runs its device work on its own high-priority
+    stream (`stream="priority"`, the default).  Same results either way; beside a long embedding call the searches of the
+    priority store take milliseconds, those of a `stream="default"` store wait for whole forwards."""
+    import time
+    import numpy as np
+    import torch
+    import coderag_amd  # noqa: F401
+    from coderag_amd.providers import HipUniXcoderProvider, ProviderConfig
+    from coderag_amd.store import HipVectorStore
+    provider = HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model="synthetic", extra={"synthetic_weights": 7}))   # 12 layers
+    rng = np.random.default_rng(13)
+    n = 300_000
+    vecs = rng.standard_normal((n, 768)).astype(np.float32)
+    pay = [{"file_path": f"/p/f{i % 100}.py", "entity_name": f"fn_{i}", "content": "x"} for i in range(n)]
+    ids = [f"id{i}" for i in range(n)]
+    texts = [("def f_%d(x):\n    return x + %d\n" % (i, i)) * 24 for i in range(6000)]          # ~400 tokens each: a few hundred ms of forwards
+    queries = vecs[rng.choice(n, 24, replace=False)]
+
+    async def run(mode):
+        async with HipVectorStore(dim=768, dtype="bf16", initial_capacity=n, stream=mode) as store:
+            await store.create_collections()
+            for a in range(0, n, 100_000):
+                await store.upsert("code_chunks", ids[a:a + 100_000], vecs[a:a + 100_000], pay[a:a + 100_000])
+            await store.search("code_chunks", queries[0].tolist(), limit=5)
+            alone = []
+            for q in queries[:8]:
+                t0 = time.perf_counter()
+                await store.search("code_chunks", q.tolist(), limit=5)
+                alone.append((time.perf_counter() - t0) * 1e3)
+            emb = asyncio.ensure_future(provider.embed_batch(texts, batch_size=len(texts)))
+            await asyncio.sleep(0.05)                                   # the embedding call is on the device by now
+            beside, hits = [], []
+            while not emb.done() and len(beside) < 200:
+                q = queries[len(beside) % len(queries)]
+                t0 = time.perf_counter()
+                hits.append([(h["id"], h["score"]) for h in await store.search("code_chunks", q.tolist(), limit=5)])
+                beside.append((time.perf_counter() - t0) * 1e3)
+            await emb
+            ref = [[(h["id"], h["score"]) for h in await store.search("code_chunks", queries[i % len(queries)].tolist(), limit=5)] for i in range(len(hits))]
+            assert hits == ref and all(h[0][1] > 0.99 for h in hits)    # the same hits, the stored row itself first
+            return float(np.median(alone)), float(np.median(beside)) if beside else None, max(beside) if beside else None, len(beside)
+    asyncio.run(provider.embed_batch(texts[:512], batch_size=512))     # load + warm the encoder
+    out = {mode: asyncio.run(run(mode)) for mode in ("default", "priority")}
+    print({k: tuple(round(x, 2) if isinstance(x, float) else x for x in v) for k, v in out.items()})
+    assert out["priority"][3] >= 5, "the embedding call ended before any search ran beside it"
+    assert out["priority"][1] <= 5.0, out                               # milliseconds, not forwards
