@@ -81,6 +81,13 @@ struct crh_index {
     int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay (its selection step costs more: 100 k
                                             // encoder embeddings took 0.38 ms per batch against 0.18 ms); CODERAG_HIP_I8_MIN_ROWS
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
+    // The validity mask of the last filter is kept while nothing it was built from has changed (rows, alive bits, codes: every
+    // mutation bumps `mutations`): the reference's searchers send the same equality filter with query after query (project_name,
+    // language: query/vector_search.py:83-93), and rebuilding the mask is a pass over the code columns per batch (~20 us at 10M rows).
+    uint64_t mutations = 1, mask_built_at = 0;
+    hipStream_t mask_stream = nullptr;   // (the stream the kept mask was built on: another stream rebuilds it -- nothing orders the two)
+    int mask_nfilt = -1;
+    crh_filter mask_filt[CRH_MAX_FILTERS];
     u32x4 *xt = nullptr;
     float *xf32 = nullptr;
     uint32_t *alive = nullptr;
@@ -190,6 +197,7 @@ int ensure_workspace(crh_index *h, crh_index::Workspace &w, int wave_cap, int qc
     if (w.ws_mask_tiles < h->cap_tiles) {
         dev_free(w.effmask);
         w.ws_mask_tiles = 0;
+        h->mask_built_at = 0;
         CRH_TRY(dev_alloc(&w.effmask, h->cap_tiles));
         w.ws_mask_tiles = h->cap_tiles;
     }
@@ -248,10 +256,18 @@ int build_mask(crh_index *h, crh_index::Workspace &w, const crh_filter *filters,
         fs.col[f] = filters[f].col;
         fs.code[f] = filters[f].code;
     }
-    const int64_t rows = (h->count + 63) & ~63LL;
-    hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, h->alive, h->codes, h->cap_rows,
-                       h->count, fs, w.effmask);
-    CRH_HIP(hipGetLastError());
+    const bool same = h->mask_built_at == h->mutations && h->mask_stream == st && h->mask_nfilt == nfilt &&
+                      memcmp(h->mask_filt, filters, sizeof(crh_filter) * (size_t)nfilt) == 0;
+    if (!same) {
+        const int64_t rows = (h->count + 63) & ~63LL;
+        hipLaunchKernelGGL(k_filter_mask, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, h->alive, h->codes, h->cap_rows,
+                           h->count, fs, w.effmask);
+        CRH_HIP(hipGetLastError());
+        h->mask_built_at = h->mutations;
+        h->mask_stream = st;
+        h->mask_nfilt = nfilt;
+        memcpy(h->mask_filt, filters, sizeof(crh_filter) * (size_t)nfilt);
+    }
     *mask_out = w.effmask;
     return CRH_OK;
 }
@@ -822,6 +838,7 @@ static int append_impl(crh_index *h, int64_t n, const float *vecs, int on_device
     h->i8_dirty_from = std::min<int64_t>(h->i8_dirty_from, h->count / kTileRows);   // (the last tile may have been partly filled)
     h->count += n;
     h->alive_count += n;
+    h->mutations += 1;
     return CRH_OK;
 }
 
@@ -840,6 +857,7 @@ int crh_index_tombstone(crh_index *h, int64_t n, const int64_t *rows)
     unsigned int cleared = 0;
     CRH_HIP(hipMemcpy(&cleared, h->scratch_u32, 4, hipMemcpyDeviceToHost));
     h->alive_count -= cleared;
+    h->mutations += 1;
     return CRH_OK;
 }
 
@@ -862,6 +880,7 @@ int crh_index_tombstone_filter(crh_index *h, const crh_filter *filters, int n_fi
     unsigned int cleared = 0;
     CRH_HIP(hipMemcpy(&cleared, h->scratch_u32, 4, hipMemcpyDeviceToHost));
     h->alive_count -= cleared;
+    h->mutations += 1;
     if (n_cleared_out) *n_cleared_out = cleared;
     return CRH_OK;
 }
@@ -955,6 +974,7 @@ int crh_index_compact(crh_index *h, int64_t *old_to_new_host, int64_t *rows_afte
 #undef CRH_CPT
     cleanup();
     h->count = new_count;
+    h->mutations += 1;
     h->i8_dirty_from = 0;
     h->alive_count = new_count;
     if (rows_after) *rows_after = new_count;
@@ -1017,6 +1037,7 @@ int crh_index_import(crh_index *h, int64_t first_tile, int64_t n_tiles, int64_t 
     for (int c = 0; c < h->ncols; ++c)
         CRH_HIP(hipMemcpy(h->codes + (int64_t)c * h->cap_rows + r0, codes_host + (int64_t)c * nr, (size_t)nr * 4, hipMemcpyHostToDevice));
     h->count = rows_after;
+    h->mutations += 1;
     h->i8_dirty_from = std::min<int64_t>(h->i8_dirty_from, first_tile);
     h->alive_count += alive_rows;
     return CRH_OK;
@@ -1041,6 +1062,7 @@ int crh_index_clear(crh_index *h)
         CRH_HIP(hipMemset(h->alive, 0, (size_t)used_tiles * 4));
     }
     h->count = 0;
+    h->mutations += 1;
     h->i8_dirty_from = 0;
     h->alive_count = 0;
     h->pending.clear();
@@ -1094,6 +1116,7 @@ int crh_index_reserve(crh_index *h, int64_t capacity_rows)
     h->alive = nalive;
     h->codes = ncodes;
     h->cap_rows = new_rows;
+    h->mutations += 1;   // (the code columns moved to their new pitch)
     h->cap_tiles = new_tiles;
     return CRH_OK;
 }

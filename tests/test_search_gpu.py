@@ -765,3 +765,63 @@ def test_65_to_128_queries_take_two_passes_over_the_int8_copy_instead_of_one_wid
         _exact(idx, x, q, 40, True)
         assert idx.stats()["batches"] == batches, (nq, idx.stats())
     idx.close()
+
+
+def test_the_kept_filter_mask_follows_every_mutation(gpu):
+    """The validity mask of the last filter is kept while nothing it was built from has changed (the reference's searchers repeat
+    one equality filter query after query).  Every mutation -- append, tombstone by row and by filter, compaction, reserve -- and a
+    change of filter or of stream must rebuild it: each search below is checked against the oracle on the state it should see."""
+    import torch
+    ffi = _ffi()
+    rng = np.random.default_rng(41)
+    n = 40_000
+    x = rng.standard_normal((n + 8_000, D), dtype=np.float32)
+    codes = rng.integers(0, 3, (n + 8_000, 2)).astype(np.int32)
+    q = rng.standard_normal((16, D), dtype=np.float32)
+    idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=n, n_code_cols=2)
+    idx.append(x[:n], codes[:n])
+    alive = np.ones(n, np.uint8)
+
+    def check(rows, filt):
+        s, r = idx.search(q, 30, filters=filt)
+        es, er = orc.cosine_search(x[:rows], q, 30, bf16=True, alive=alive[:rows], codes=codes[:rows], filters=filt)
+        assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+        return r
+    f1, f2 = [(0, 1)], [(0, 1), (1, 2)]
+    r = check(n, f1)
+    assert np.array_equal(check(n, f1), r)                      # the kept mask: same answer
+    check(n, f2)
+    check(n, f1)
+    idx.tombstone(r[:, 0])                                      # the best hit of every query goes
+    alive[r[:, 0]] = 0
+    r2 = check(n, f1)
+    assert not np.isin(r2, r[:, 0]).any()
+    hit = np.flatnonzero((codes[:n, 0] == 1) & (codes[:n, 1] == 0) & (alive == 1))
+    assert idx.tombstone_filter([(0, 1), (1, 0)]) == len(hit)
+    alive[hit] = 0
+    check(n, f1)
+    idx.reserve(n + 8_000)                                      # reallocation: code columns at a new pitch
+    check(n, f1)
+    idx.append(x[n:], codes[n:])
+    alive = np.concatenate([alive, np.ones(8_000, np.uint8)])
+    check(n + 8_000, f1)
+    # device outputs on two different streams, back to back: the second stream does not trust the first one's mask
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(q).to(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = []
+    for st in (s1, s2, s1):
+        os_ = torch.empty((16, 30), dtype=torch.float32, device=dev)
+        or_ = torch.empty((16, 30), dtype=torch.int64, device=dev)
+        idx.search(qd, 30, filters=f1, out_scores=os_, out_rows=or_, stream=st.cuda_stream)
+        idx.search_finish(st.cuda_stream)
+        outs.append((os_.cpu().numpy(), or_.cpu().numpy()))
+    es, er = orc.cosine_search(x, q, 30, bf16=True, alive=alive, codes=codes, filters=f1)
+    for s_, r_ in outs:
+        assert np.array_equal(r_, er) and np.array_equal(s_.view(np.uint32), es.view(np.uint32))
+    o2n = idx.compact()
+    keep = np.flatnonzero(alive)
+    s, r = idx.search(q, 30, filters=f1)
+    es, er = orc.cosine_search(x[keep], q, 30, bf16=True, codes=codes[keep], filters=f1)
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32)) and np.array_equal(o2n[keep], np.arange(len(keep)))
+    idx.close()
