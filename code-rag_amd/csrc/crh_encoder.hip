@@ -19,6 +19,9 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifndef CRH_ATTN_PERMLANE
+#define CRH_ATTN_PERMLANE 1
+#endif
 #include "crh_common.h"
 
 namespace crh {
@@ -566,6 +569,37 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 
 // ------------------------------------------------------------------ attention
 
+// The value of lane (l ^ 16) / (l ^ 32), by ONE v_permlane16_swap / v_permlane32_swap (gfx950) instead of __shfl_xor's
+// ds_bpermute_b32: no address arithmetic, no trip through the LDS crossbar and no lgkmcnt wait in a loop whose issue slots are
+// what bounds it (the softmax's two row reductions cross the four 16-lane groups of a wave twice per key tile).
+// permlane16_swap(a, b) exchanges a's odd 16-lane rows with b's even ones; with a = b = x the pair (a', b') holds, in every lane,
+// x of its own row pair's even row and odd row: its own value and its xor-16 partner's, in some order -- which is all a sum or a
+// maximum needs (a + b and b + a are the same bits).  Likewise for the two halves of the wave.
+#if CRH_ATTN_PERMLANE
+// (Written as inline asm: with ROCm 7.2's clang the builtin __builtin_amdgcn_permlane16_swap(u, u, ...) hands back ITS FIRST result for
+// both elements when the two operands carry the same value -- found with tools/scratch/permlane_check*.hip; the asm form was checked
+// against __shfl_xor there, bit for bit.  The s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see inside asm.)
+template <bool SUM>
+__device__ __forceinline__ float join16(float x)     // x (+ or max) the value of lane l ^ 16: own and partner end up in a and b, in some order
+{
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {R0, R0, R2, R2}, b = {R1, R1, R3, R3}
+    return SUM ? a + b : fmaxf(a, b);
+}
+template <bool SUM>
+__device__ __forceinline__ float join32(float x)
+{
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {lo, lo}, b = {hi, hi}
+    return SUM ? a + b : fmaxf(a, b);
+}
+#else
+template <bool SUM>
+__device__ __forceinline__ float join16(float x) { const float y = __shfl_xor(x, 16); return SUM ? x + y : fmaxf(x, y); }
+template <bool SUM>
+__device__ __forceinline__ float join32(float x) { const float y = __shfl_xor(x, 32); return SUM ? x + y : fmaxf(x, y); }
+#endif
+
 // grid = (H, B), block = NW*64.  qkv bf16 [B*L][3*H*64] (q | k | v thirds, head-major inside a third); out bf16 [B*L][H*64].
 // Dynamic LDS: K image [L][64] then V image [L][64], both 128-B rows with the chunk XOR of lds_off().
 template <int NW, int QT>
@@ -673,8 +707,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
                             mloc = fmaxf(mloc, v);
                         }
                 }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                mloc = join32<false>(join16<false>(mloc));
                 const float mnew = fmaxf(mrun[qi], mloc);  // raw-score maximum; finite: vm != 0 guarantees a valid key in this tile
                 const float alpha = __builtin_amdgcn_exp2f((mrun[qi] - mnew) * scale_log2);   // first tile: 2^-inf = 0
                 const float nb = -mnew * scale_log2;
@@ -695,8 +728,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const bf16_t *__restrict__ qkv
                     pb[qi][s2] = __builtin_bit_cast(bf16x8, pk);
                 }
                 float psum = ps2.x + ps2.y;
-                psum += __shfl_xor(psum, 16);
-                psum += __shfl_xor(psum, 32);
+                psum = join32<true>(join16<true>(psum));
                 lrun[qi] = lrun[qi] * alpha + psum;
                 mrun[qi] = mnew;
                 const f32x2_t al2 = {alpha, alpha};
