@@ -154,7 +154,7 @@ class SummarySearchResult:
 
 
 class VectorIndexer:
-    GROUP, GROUP_FIRST = 8192, 1024      # chunks per pipelined group of index_files_batched: the first group / the largest
+    GROUP, GROUP_FIRST = 4096, 512       # chunks per pipelined group of index_files_batched: the largest / the first
 
     def __init__(self, qdrant, embedder, chunker=None):
         self.qdrant = qdrant

@@ -168,7 +168,7 @@ class HipUniXcoderProvider(BaseEmbeddingProvider):
             return np.zeros((0, self.EMBEDDING_DIM), np.float32)
         try:
             self.submissions += 1
-            return np.asarray(self._load().embed_texts(list(texts), max_length=self.max_length, rows="numpy"), dtype=np.float32)
+            return self._load().embed_texts(list(texts), max_length=self.max_length, rows="array")
         except Exception as e:
             raise EmbeddingError("HIP UniXcoder embedding failed", cause=e)
 

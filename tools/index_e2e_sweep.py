@@ -67,7 +67,7 @@ async def stages():
 
 
 async def sweep():
-    for group, first in ((8192, 1024), (8192, 512), (8192, 2048), (4096, 1024), (8192, 8192), (1 << 30, 1 << 30)):
+    for group, first in ((4096, 512), (4096, 512), (8192, 512), (4096, 1024), (2048, 512), (8192, 8192), (1 << 30, 1 << 30)):
         VectorIndexer.GROUP, VectorIndexer.GROUP_FIRST = group, first
         async with HipVectorStore(dim=768, dtype="bf16", initial_capacity=1 << 16) as store:
             await store.create_collections()
