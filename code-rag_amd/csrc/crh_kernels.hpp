@@ -45,7 +45,6 @@ struct SearchStatus {
     unsigned int next_chunk;     // k_scan_i8: tile chunks handed out so far beyond each workgroup's first (zeroed with the slot)
     unsigned int qcount[kWideQ];  // per-query candidate counters of the batch (the whole slot is zeroed by k_prep_queries)
     unsigned int qsurv[kMaxQ];    // k_select behind the int8 scan, several workgroups per query: fast-scored survivors published so far
-    unsigned int qdone[kMaxQ];    // (unused since round 4: the kernel boundary before k_select_final is the meeting point)
     unsigned int qsurv2[kMaxQ];   // k_select_final, several workgroups per query: canonical keys published so far ...
     unsigned int qdone2[kMaxQ];   // ... and workgroups that have published (the last one ranks)
 };

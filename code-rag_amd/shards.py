@@ -10,8 +10,8 @@ delete / count / match by filter, search, compact, save / load -- and spreads th
   calls and owns shard ``rank``: its rows' vectors, and -- since round 4 -- their embedding work and their payload TEXT
   (``append`` takes the rows of the owned shards only; ``exchange_bytes`` completes what only an owner holds).  Ids, the coded
   payload columns and the slot maps stay replicated.  The search is the path of ``sharded.ShardedIndex``: local scan with
-  ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.  Control-plane results (counts, matching
-  rows, compaction maps) travel as small host objects; what a search returns travels in tensor collectives only.
+  ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.  Counts, matching rows and compaction maps travel in tensor
+  collectives as well (round 4; a compaction map is one entry per row); only the agreement on a FAILED append is a small host object.
 
 Rows are dealt to the shards in blocks of ``block`` rows, round robin, so shards stay balanced under incremental upserts.
 A row's global id is ``shard * STRIDE + local row`` (``STRIDE`` = 2^32, a ``crh_index`` holds at most 2^31 rows): stable under
@@ -75,12 +75,48 @@ class ShardSet:
         self.dist.all_gather_object(out, mine, group=self.group)
         return out
 
+    def _tensor_device(self):
+        import torch
+        return torch.device("cuda", self.device) if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def _sum_everyone(self, value: int) -> int:
+        """Sum of one integer per rank: ONE tensor all-reduce (counts of deleted / matching / alive rows)."""
+        if self.dist is None:
+            return int(value)
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._tensor_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    def _arrays_everyone(self, mine: dict[int, np.ndarray]) -> dict[int, np.ndarray]:
+        """{shard: int64 array} of every rank, united -- two tensor collectives (lengths, then the padded arrays) instead of
+        pickled objects: compaction maps are one entry per ROW (80 MB per 10M-row shard)."""
+        if self.dist is None:
+            return {s: np.asarray(a, np.int64) for s, a in mine.items()}
+        import torch
+        dev = self._tensor_device()
+        arr = np.asarray(mine[self.rank], np.int64) if self.rank in mine else np.zeros((0,), np.int64)
+        lens = torch.zeros((self.ns,), dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(lens, torch.tensor([arr.size], dtype=torch.int64, device=dev), group=self.group)
+        lens_h = lens.cpu().numpy()
+        width = max(1, int(lens_h.max()))
+        pad = np.zeros((width,), np.int64)
+        pad[:arr.size] = arr
+        out = torch.empty((self.ns, width), dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(out.view(-1), torch.from_numpy(pad).to(dev), group=self.group)
+        out_h = out.cpu().numpy()
+        return {r: out_h[r, : int(lens_h[r])].copy() for r in range(self.ns)}
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
+
     @property
     def capacity_rows(self) -> int:
         return sum(ix.capacity_rows for ix in self.index.values())
 
     def count(self) -> tuple[int, int]:
-        alive = sum(self._everyone(sum(ix.count()[1] for ix in self.index.values())))
+        alive = self._sum_everyone(sum(ix.count()[1] for ix in self.index.values()))
         return sum(self.rows), int(alive)
 
     # ------------------------------------------------------------------ build
@@ -199,18 +235,15 @@ class ShardSet:
                 ix.tombstone(np.asarray(sel, np.int64))
 
     def tombstone_filter(self, dfilt) -> int:
-        return int(sum(self._everyone(sum(ix.tombstone_filter(dfilt) for ix in self.index.values()))))
+        return self._sum_everyone(sum(ix.tombstone_filter(dfilt) for ix in self.index.values()))
 
     def count_matching(self, dfilt) -> int:
-        return int(sum(self._everyone(sum(ix.count_matching(dfilt) for ix in self.index.values()))))
+        return self._sum_everyone(sum(ix.count_matching(dfilt) for ix in self.index.values()))
 
     def match_rows(self, dfilt, limit: int) -> tuple[np.ndarray, np.ndarray]:
         """(shard, local row) of up to ``limit`` alive matching rows PER SHARD, ascending inside each shard (a caller that wants
         the first ``limit`` in insertion order sorts the union by slot and cuts)."""
-        mine = {s: ix.match_rows(dfilt, limit) for s, ix in self.index.items()}
-        allr: dict[int, np.ndarray] = {}
-        for part in self._everyone(mine):
-            allr.update(part)
+        allr = self._arrays_everyone({s: ix.match_rows(dfilt, limit) for s, ix in self.index.items()})
         sh = np.concatenate([np.full((len(allr[s]),), s, np.int32) for s in sorted(allr)]) if allr else np.zeros((0,), np.int32)
         lo = np.concatenate([np.asarray(allr[s], np.int64) for s in sorted(allr)]) if allr else np.zeros((0,), np.int64)
         return sh, lo
@@ -279,10 +312,7 @@ class ShardSet:
     # ------------------------------------------------------------------ maintenance
     def compact(self) -> dict[int, np.ndarray]:
         """``crh_index_compact`` on every shard; returns {shard: old_to_new local rows} for ALL shards on every rank."""
-        mine = {s: ix.compact() for s, ix in self.index.items()}
-        maps: dict[int, np.ndarray] = {}
-        for part in self._everyone(mine):
-            maps.update(part)
+        maps = self._arrays_everyone({s: ix.compact() for s, ix in self.index.items()})
         for s, o2n in maps.items():
             self.rows[s] = int((o2n >= 0).sum())
         return maps
@@ -301,10 +331,8 @@ class ShardSet:
     def load(self, directory: str) -> None:
         for s, ix in self.index.items():
             ix.load(directory if self.ns == 1 else os.path.join(directory, f"shard{s}"))
-        counts: dict[int, int] = {}
-        for part in self._everyone({s: ix.count()[0] for s, ix in self.index.items()}):
-            counts.update(part)
-        self.rows = [int(counts[s]) for s in range(self.ns)]
+        counts = self._arrays_everyone({s: np.asarray([ix.count()[0]], np.int64) for s, ix in self.index.items()})
+        self.rows = [int(counts[s][0]) for s in range(self.ns)]
 
     def close(self) -> None:
         for ix in self.index.values():

@@ -384,7 +384,7 @@ class _Collection:
         if primary:
             shutil.rmtree(tmp, ignore_errors=True)
             os.makedirs(tmp, exist_ok=True)
-        self.shards._everyone(None)                               # (every rank sees the directory before writing into it)
+        self.shards.barrier()                                     # (every rank sees the directory before writing into it)
         self.shards.save(tmp)
         if self.partial:                                          # a rank's payload table holds the text of its own rows only: one table per rank
             sub = os.path.join(tmp, f"tables{self.shards.rank}")
@@ -399,11 +399,11 @@ class _Collection:
             with open(os.path.join(tmp, "collection.json"), "w") as f:
                 json.dump({"name": self.name, "keys": list(self.keys), "format": 3, "slots": self.payloads.n, "shards": self.shards.ns,
                            "shard_rows": list(self.shards.rows), "degrees": self._degrees}, f, default=repr)
-        self.shards._everyone(None)
+        self.shards.barrier()
         if primary:
             shutil.rmtree(directory, ignore_errors=True)
             os.replace(tmp, directory)
-        self.shards._everyone(None)
+        self.shards.barrier()
 
     def load(self, directory: str) -> None:
         import json
@@ -517,7 +517,8 @@ class _RawClient:
             if ok:
                 slots.append(int(t))
         if col.partial:
-            slots = sorted(t for part in col.shards._everyone(slots) for t in part)
+            parts = col.shards._arrays_everyone({col.shards.rank: np.asarray(slots, np.int64)})
+            slots = sorted(int(t) for part in parts.values() for t in part)
         return np.asarray(slots, dtype=np.int64)
 
     async def count(self, collection_name: str, count_filter=None, exact: bool = True):
