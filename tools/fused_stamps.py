@@ -2,7 +2,8 @@
 """Where k_scan_fused spends its time before the main loop: per-workgroup wall-clock stamps (100 MHz) taken by a measurement
 build of the library (tools/build_stamps_lib.sh: -DCRH_FUSED_STAMPS -> lib/libcoderag_hip_stamps.so; not part of build.sh):
 0 kernel entry, 1 query image in LDS, 2 sample tile done, 3 past wait A, 4 threshold written, 5 past wait B, 6 main loop done.
-CODERAG_HIP_LIB=code-rag_amd/lib/libcoderag_hip_stamps.so python tools/fused_stamps.py [rows]"""
+CODERAG_HIP_LIB=code-rag_amd/lib/libcoderag_hip_stamps.so python tools/fused_stamps.py [rows]
+STAMPS_FILTER=1: the batches carry the filter "code column 0 == 1" over three uniform codes (the bench's `filtered` leg)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,11 +12,13 @@ from coderag_amd import ffi
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dev = torch.device("cuda:0"); D, B, K = 768, 64, 100
 st = torch.cuda.current_stream().cuda_stream
-idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=rows, device=0)
+flt = [(0, 1)] if os.environ.get("STAMPS_FILTER") == "1" else None
+idx = ffi.Index(D, ffi.DTYPE_BF16, capacity_rows=rows, device=0, n_code_cols=1 if flt else 0)
 gen = torch.Generator(device=dev); gen.manual_seed(20251226)
 for r0 in range(0, rows, 500_000):
     m = min(500_000, rows - r0)
-    idx.append(torch.randn((m, D), generator=gen, device=dev), stream=st)
+    idx.append(torch.randn((m, D), generator=gen, device=dev),
+               torch.randint(0, 3, (m, 1), generator=gen, device=dev, dtype=torch.int32) if flt else None, stream=st)
     torch.cuda.synchronize()
 qd = torch.randn((B, D), generator=gen, device=dev)
 s = torch.empty((B, K), dtype=torch.float32, device=dev); r = torch.empty((B, K), dtype=torch.int64, device=dev)
@@ -26,7 +29,7 @@ sel = []
 acc = []
 wacc = []
 for it in range(12):
-    idx.search(qd, K, out_scores=s, out_rows=r, stream=st)
+    idx.search(qd, K, filters=flt, out_scores=s, out_rows=r, stream=st)
     idx.search_finish(st)
     buf = np.zeros(256 * 24, np.uint64)
     assert L.crh_debug_fused_stamps(buf.ctypes.data) == 0
