@@ -193,22 +193,27 @@ __device__ __forceinline__ void prep_query_i8(const float *src /* the canonical 
     }
 }
 
-// ------------------------------------------------------------------ the scan over the int8 copy, one launch
-// Phases as k_scan_fused (sample tiles -> grid-wide wait -> thresholds -> grid-wide wait -> all tiles), with two differences:
-// the sample is G = min(8192, tiles) strided tiles walked by whoever's turn it is (the accumulators are not kept across the
-// waits: four accumulator sets per wave leave no room, and re-reading 200 MB of samples costs 2.6 % of the pass), and the
-// per-row interval arithmetic of the header comment replaces the single score.
-// LDS: query image QB * 2 * KS8 KiB (96 KB at D = 768) + the threshold phase's 16 + 8 + 5 KB.  WAVES = 8: 64 accumulator
-// registers + a 16-deep ring of loads per wave need more than the 128 registers a 16-wave workgroup leaves each wave.
-template <int KS8, int WAVES, int RING, int QB>
+// ------------------------------------------------------------------ the scan over the int8 copy
+// Phases as k_scan_fused (sample tiles -> thresholds -> all tiles), with two differences: the sample is G = min(8192, tiles)
+// strided tiles walked by whoever's turn it is (the pass reads them again: 200 MB, 2.6 % of it), and the per-row interval
+// arithmetic of the header comment replaces the single score.
+// LDS: query image QB * 2 * KS8 KiB (96 KB at D = 768) in parts 1 and 3; the threshold step's 32 + 8 + 5 KB in part 2.  WAVES = 8:
+// 64 accumulator registers + a 16-deep ring of loads per wave need more than the 128 registers a 16-wave workgroup leaves each wave.
+// Three launches of one kernel body -- PART 1: the sample tiles, 2: the thresholds (one workgroup per query), 3: the pass over all
+// tiles and the hand-over of the candidates.  Until late in round 4 the three were ONE launch with two grid-wide waits (the form
+// k_scan_fused still has): the waits, during which 3/4 of the workgroups idle, cost more than the two launch boundaries that replace
+// them (1.325 -> 1.312 ms per batch and 1.383 -> 1.377 on two boxes, interleaved pairs), and a kernel without a grid-wide wait
+// needs nobody resident: no time-out, no recovery path, no resting window for this scan.
+template <int KS8, int WAVES, int RING, int QB, int PART>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const u32x4 *__restrict__ x8, const float *__restrict__ srow, const unsigned int *__restrict__ dn_bits,
     const u32x4 *__restrict__ qfrag8, const float *__restrict__ qpar, const uint32_t *__restrict__ rowmask, int ntiles, int G, int S,
     uint32_t *__restrict__ gkey, float *__restrict__ tau_g, int k, float c_abs, float sqrt_dim, int nq, u32x4 *__restrict__ wave_lists,
     int wave_cap, unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, float *__restrict__ qlo, int qcap,
-    SearchStatus *__restrict__ status, int wait_extra, const u32x4 *__restrict__ xt, const float *__restrict__ xf32,
-    const float *__restrict__ qn, const u32x4 *__restrict__ xrow, unsigned int wait_ticks)
+    SearchStatus *__restrict__ status, const u32x4 *__restrict__ xt, const float *__restrict__ xf32,
+    const float *__restrict__ qn, const u32x4 *__restrict__ xrow)
 {
+    static_assert(PART >= 1 && PART <= 3, "sample tiles / thresholds / pass");
     static_assert(KS8 % RING == 0, "the ring must divide the pieces of a tile (slot s % RING holds piece s of every tile)");
     constexpr int NT = WAVES * 64, NQS = QB * 32, NB = NT < 1024 ? NT : 1024;
     __shared__ u32x4 qs[QB * 2 * KS8 * 64];
@@ -236,9 +241,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     if (tid == 0) {
         next_m = WAVES;
         next_g = WAVES;
-        for (int j = 2; j < 8; ++j) cslot[j] = ~0ull;
-        cslot[0] = (unsigned long long)blockIdx.x;
-        cslot[1] = (1ull << 32) | (gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if constexpr (PART == 3) {
+            for (int j = 2; j < 8; ++j) cslot[j] = ~0ull;
+            cslot[0] = (unsigned long long)blockIdx.x;
+            cslot[1] = (1ull << 32) | (gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
     }
     // per-lane constants of the lane's query in each block: s_q and B_q (integer-dot units)
     const float dn = bits_f32(*dn_bits);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     };
 
     // ---- 1. sample tiles g = gw, gw + total, ...: per query the largest LOWER end among the tile's valid rows
-    {
+    if constexpr (PART == 1) {
         int g = gw;
         if (g < G) prime(tile_ptr((int64_t)g * S));
         // the query image comes in behind the first corpus loads: 96 KB per workgroup that the first tile would otherwise wait for
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             const int gn_ = (mg / WAVES) * total + (int)blockIdx.x * WAVES + (mg % WAVES);
             const int64_t tile = (int64_t)g * S;
             const u32x4 *xp = tile_ptr(tile);
-            const u32x4 *xn = gn_ < G ? tile_ptr((int64_t)gn_ * S) : (gw < ntiles ? tile_ptr(gw) : xp);
+            const u32x4 *xn = gn_ < G ? tile_ptr((int64_t)gn_ * S) : xp;   // (past the last sample tile: its own pieces again, unused)
             const uint32_t vmask = rowmask[tile];
             float sr[32];
 #pragma unroll
@@ -400,11 +407,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             }
             g = gn_;
         }
-        if (gw >= G && gw < ntiles) prime(tile_ptr(gw));   // waves without a sample tile: start the main stream now
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last sample tile's run-ahead loads)
+        return;
     }
-    CRH_STAMP(2);
-    grid_wait(&status->bar_a, gridDim.x + wait_extra, true, status, wait_ticks);
-    CRH_STAMP(3);
 
     // ---- 2. thresholds: workgroup q owns query q (no margin: the intervals carry it)
     // The k tiles with the largest lower ends name k distinct rows; their scores are then worked out from the STORED rows (any
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     constexpr int SELCAP = 384;                           // k <= 256 (kI8MaxK) + room for equal keys
     static_assert(NB + 256 + 2 * (NT / 64) + 8 >= 2 * SELCAP, "sel / selv overlay the scratch of wg_kth_largest_fast");
     static_assert((NT / 64) * 256 >= KS8 * 32, "the canonical query overlays the radix histograms");
+    if constexpr (PART == 2)
     for (int q = blockIdx.x; q < NQS; q += gridDim.x) {
         float t = -INFINITY;
         if (q >= nq) {
@@ -494,9 +500,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
         }
         if (tid == 0) tau_g[q] = t;
     }
-    const unsigned int producers = gridDim.x < (unsigned int)NQS ? gridDim.x : (unsigned int)NQS;
-    CRH_STAMP(4);
-    grid_wait(&status->bar_b, producers, blockIdx.x < producers, status, wait_ticks);
+    if constexpr (PART == 2) return;
+    // ---- 3. the pass: the first corpus loads, then the query image behind them
+    if (gw < ntiles) prime(tile_ptr(gw));
+    for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
     CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
     __syncthreads();
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 #pragma unroll
     for (int b = 0; b < QB; ++b) tq[b] = tau_s[b * 32 + (lane & 31)];
 
-    // ---- 3. every tile: rows whose UPPER end reaches the query's threshold become candidates (hi, row, query, lo)
+    // every tile: rows whose UPPER end reaches the query's threshold become candidates (hi, row, query, lo)
     int i = gw;
     const u32x4 *xp = tile_ptr(i < ntiles ? i : 0);
     while (i < ntiles) {

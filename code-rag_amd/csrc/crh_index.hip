@@ -325,7 +325,8 @@ int launch_scan_fused(crh_index *h, crh_index::Workspace &w, int blocks, hipStre
 constexpr int kI8MaxK = 256;   // beyond this k the threshold sits so low that the int8 intervals nominate several 100 k rows per query
 bool i8_use(const crh_index *h, int nq, int k)
 {
-    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_cooldown == 0 && nq <= h->batch_q && h->fused_scan && !h->fused_resting() &&
+    // (three launches, no grid-wide wait: an index resting from a time-out of the one-launch bf16 scan still nominates from the copy)
+    return k <= kI8MaxK && h->i8 && h->nominate_max >= CRH_NOMINATE_INT8 && !h->i8_suppress && h->i8_cooldown == 0 && nq <= h->batch_q && h->fused_scan &&
            (h->seed_tiles == 4096 || h->seed_tiles == kI8SampleTiles) && h->count >= h->i8_min_rows;
 }
 
@@ -380,18 +381,20 @@ int i8_sync(crh_index *h, hipStream_t st)
     return CRH_OK;
 }
 
+// PART 1: the sample tiles, 2: the thresholds (one workgroup per query), 3: the pass -- three launches, stream order between them
+template <int PART>
 int launch_scan_i8(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int ntiles, int G, int S, int k, float c_abs,
                    int nq, int wave_cap, int qcap, SearchStatus *stt)
 {
 #define CRH_I8(KS8, RING, QB)                                                                                                          \
-    hipLaunchKernelGGL((k_scan_i8<KS8, kI8Waves, RING, QB>), dim3(blocks), dim3(kI8Waves * 64), 0, st, h->x8, h->srow, h->i8stat, w.qfrag8, \
-                       w.qpar, mask, ntiles, G, S, reinterpret_cast<uint32_t *>(w.gmax), w.tau, k, c_abs, sqrtf((float)h->dim), nq, w.wave_lists,    \
-                       wave_cap, stt->qcount, w.qlist, w.qlo, qcap, stt, h->force_fallback == 2 ? 1 : 0, h->xt,                                \
-                       h->dtype == CRH_DTYPE_F32 ? h->xf32 : (const float *)nullptr, w.qn, h->xrow,                                             \
-                       wait_ticks_for((double)ntiles * (h->dim / 32) * 1024.0))
+    hipLaunchKernelGGL((k_scan_i8<KS8, kI8Waves, RING, QB, PART>), dim3(PART == 2 ? QB * 32 : blocks), dim3(kI8Waves * 64), 0, st, h->x8, h->srow, \
+                       h->i8stat, w.qfrag8, w.qpar, mask, ntiles, G, S, reinterpret_cast<uint32_t *>(w.gmax), w.tau, k, c_abs, sqrtf((float)h->dim), \
+                       nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, w.qlo, qcap, stt, h->xt,                                               \
+                       h->dtype == CRH_DTYPE_F32 ? h->xf32 : (const float *)nullptr, w.qn, h->xrow)
     switch (h->dim) {
     case 384: CRH_I8(12, 12, 2); break;
     case 768: CRH_I8(24, kI8Ring, 2); break;
+    case 1024: CRH_I8(32, kI8Ring, 2); break;   // (128 KB of query image: fits since the threshold step is a launch of its own)
     case 1536: CRH_I8(48, kI8Ring, 1); break;
     default: return fail(CRH_E_INTERNAL, "no int8 scan kernel for dim %d", h->dim);
     }
@@ -465,8 +468,10 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         // what separates a row's canonical score from the exact dot of the QUANTISED-FROM rows and the canonical query: the two f32
         // summation orders only -- the copy of an f32 store is quantised from its f32 master, not from the bf16 tiles
         const float c_abs = 1.5e-4f * (h->dim > 768 ? (float)h->dim / 768.f : 1.f) + 1e-5f;
-        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));
-        CRH_TRY(launch_scan_i8(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        CRH_TRY(launch_scan_i8<1>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        CRH_TRY(launch_scan_i8<2>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));     // (the dominant kernel: the pass)
+        CRH_TRY(launch_scan_i8<3>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
         // (k_select's margin behind this scan: twice what separates a row's score summed in any order from its canonical score)
         if (h->dtype == CRH_DTYPE_F32)
@@ -702,7 +707,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         const char *e = getenv("CODERAG_HIP_FUSED_SCAN");
         h->fused_scan = !(e && e[0] == '0');
         const char *e8 = getenv("CODERAG_HIP_I8");
-        h->i8 = h->fused_scan && dim != 1024 && !(e8 && e8[0] == '0');   // (dim 1024: the query image + the threshold phase exceed LDS)
+        h->i8 = h->fused_scan && !(e8 && e8[0] == '0');
         if (h->i8) h->qcap = 131072;   // ~21 k candidates per query and 10M Gaussian rows behind the int8 scan (37 k with 4096 sample tiles)
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
         if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));

@@ -179,7 +179,7 @@ int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_lau
 /* Tuning knobs (0 / negative = keep default): seed sample tiles, per-wave candidate
  * capacity, per-query candidate capacity, force_fallback (testing): 1 = start from tiny candidate buffers so the
  * regrow-and-rerun path runs (behind the int8 scan: its one regrowth), 3 = the same with that regrowth refused (its batches go to
- * the bf16 scan: the strike path), 2 = make the one-launch scan's grid-wide wait time out so its recovery path runs, 0 = off. */
+ * the bf16 scan: the strike path), 2 = make the one-launch bf16 scan's grid-wide wait time out so its recovery path runs, 0 = off. */
 int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int query_cand_cap,
                          int force_fallback);
 
@@ -188,13 +188,15 @@ int crh_index_set_tuning(crh_index *h, int seed_tiles, int wave_cand_cap, int qu
  * stored rows whatever the mode; results are bit-identical across modes):
  *   CRH_NOMINATE_BF16_3  seed scan, threshold, main scan over the bf16 tiles as three launches
  *   CRH_NOMINATE_BF16    the same in one launch (grid-wide waits; needs the whole grid resident)
- *   CRH_NOMINATE_INT8    one launch over the int8 copy of the rows (half the bytes of the pass; +1 byte per element and 4 per
- *                        row of device memory, and for a bf16 store +2 bytes per element for the row-major rows its selection step
- *                        reads -- all derived from the stored rows, never part of a snapshot) -- the default where it exists
- *                        (dim 384 / 768 / 1536), from 1M rows up, for k <= 256.
- * set: the most advanced mode the index may use.  It still falls back by itself: no memory for the copy; a grid-wide wait that
- * timed out (the wait is bounded by eight times the pass's own time, at least 2 ms; the batch is run again in the three-launch
- * form and the index stays on it for 0.2 s, doubling with every further time-out up to 5 s); int8 candidate buffers that
+ *   CRH_NOMINATE_INT8    sample tiles, thresholds and the pass over the int8 copy of the rows, three launches, no grid-wide
+ *                        wait (half the bytes of the pass; +1 byte per element and 4 per row of device memory, and for a bf16
+ *                        store +2 bytes per element for the row-major rows its selection step reads -- all derived from the
+ *                        stored rows, never part of a snapshot) -- the default at every supported dim, from 1M rows up, for
+ *                        k <= 256.
+ * set: the most advanced mode the index may use.  It still falls back by itself: no memory for the copy; a grid-wide wait of
+ * the one-launch bf16 scan that timed out (the wait is bounded by eight times the pass's own time, at least 2 ms; the batch is
+ * run again in the three-launch form and the index stays off the one-launch form for 0.2 s, doubling with every further time-out
+ * up to 5 s -- the int8 nomination, which waits for nobody, stays in use); int8 candidate buffers that
  * overflowed (they grow ONCE to the observed need when that is at most 2 % of the rows per query; otherwise the batch goes to the
  * bf16 scan, and three such batches in a row rest the copy for 4096 batches, then one more try).  get: the mode the next batch
  * would use. */

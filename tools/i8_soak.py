@@ -12,7 +12,7 @@ from coderag_amd import ffi
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(2026)
 bad = total = gave_way = 0
-for dim, n in ((768, 300_000), (384, 200_000), (1536, 120_000)):
+for dim, n in ((768, 300_000), (384, 200_000), (1024, 150_000), (1536, 120_000)):
     for dtype in (ffi.DTYPE_BF16, ffi.DTYPE_F32):
         x = rng.standard_normal((n, dim), dtype=np.float32)
         # a tenth of the rows: heavy-tailed elements, a few dominated by one element, some exact duplicates, some tiny
