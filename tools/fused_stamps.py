@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where k_scan_fused spends its time before the main loop: per-workgroup wall-clock stamps (100 MHz) taken by a measurement
+"""Where the scans spend their time (k_scan_fused: before the main loop; k_scan_i8: inside the pass and the threshold launch): per-workgroup wall-clock stamps (100 MHz) taken by a measurement
 build of the library (tools/build_stamps_lib.sh: -DCRH_FUSED_STAMPS -> lib/libcoderag_hip_stamps.so; not part of build.sh):
 0 kernel entry, 1 query image in LDS, 2 sample tile done, 3 past wait A, 4 threshold written, 5 past wait B, 6 main loop done.
 CODERAG_HIP_LIB=code-rag_amd/lib/libcoderag_hip_stamps.so python tools/fused_stamps.py [rows]
@@ -42,6 +42,14 @@ for it in range(12):
 names = ["query image", "sample tile", "wait A", "threshold", "wait B", "main loop"]
 a = np.stack(acc)                                    # [runs, wg, stamp]
 t0 = a[:, :, 0].min(axis=1, keepdims=True)           # the first workgroup's entry
+three = idx.nomination() == ffi.NOMINATE_INT8        # the int8 scan is three launches: the stamps below are those of its LAST one, the pass
+if three:
+    print("int8-nominated batches: sample tiles, thresholds and the pass are three launches (their durations: tools/i8_timeline.py on a kernel "
+          "trace); the stamps are the pass's -- 0 entry, 5 query image and thresholds in LDS, 6 main loop done -- and the threshold launch's sub-stamps")
+    for i, n in ((5, "loop start"), (6, "main loop")):
+        v = (a[:, :, i] - t0) / 100.0
+        print(f"  {i} {n:12s} {v.min(axis=1).mean():9.1f} {np.median(v, axis=1).mean():9.1f} {v.max(axis=1).mean():9.1f}   (us after the first workgroup's entry: min / median / max)")
+    a[:, :, 1:5] = a[:, :, :1]                       # (stamps 1..4 belong to the one-launch scans only)
 print("stamp (us after the first workgroup's entry): min / median / max over workgroups, mean over runs")
 for i in range(7):
     v = (a[:, :, i] - t0) / 100.0
@@ -54,11 +62,10 @@ tauwg = d[:, :B, 3]; rest = d[:, B:, 3]
 print(f"threshold phase: workgroups 0..{B-1} (one query each) median {np.median(tauwg):.1f} us, the others {np.median(rest):.1f} us")
 w = (np.stack(wacc) - t0[:, :, None]) / 100.0            # [runs, wg, wave]: end of each wave's main loop
 wa = np.stack(wacc)
-if (wa[:, :B, 8:13] > 0).all():      # k_scan_i8: sub-stamps of the threshold phase of workgroups 0..63 (slots 8..12)
-    base = a[:, :B, 3]               # past wait A
-    tt = (wa[:, :B, 8:13] - base[:, :, None]) / 100.0
-    print("threshold phase of a query's workgroup, us after wait A -- keys in LDS / k-th largest key / rows selected / their scores / k-th largest score: "
-          + " ".join(f"{np.median(tt[:, :, i]):.1f}" for i in range(5)))
+if (wa[:, :B, 8:13] > 0).all():      # k_scan_i8: sub-stamps of the threshold launch's workgroups 0..63 (slots 8..12)
+    tt = (wa[:, :B, 9:13] - wa[:, :B, 8:9]) / 100.0
+    print("threshold launch, a query's workgroup, us after its keys were in LDS -- k-th largest key / rows selected / their scores / k-th largest score: "
+          + " ".join(f"{np.median(tt[:, :, i]):.1f}" for i in range(4)))
     w = w[:, :, :8]
 print("end of the main loop per wave slot (us after kernel entry), median over workgroups and runs:")
 print("  " + " ".join(f"{np.median(w[:, :, i]):7.0f}" for i in range(w.shape[2])))
