@@ -492,7 +492,8 @@ class Index:
         check(lib().crh_search_get_stats(self._handle(), C.byref(s)))
         return s.as_dict()
 
-    def set_profiling(self, enable: bool) -> None:
+    def set_profiling(self, enable) -> None:
+        """True / 1: HIP events around the dominant kernel of every batch; 2: around all three launches of the int8 scan."""
         check(lib().crh_index_set_profiling(self._handle(), int(enable)))
 
     def profile(self) -> tuple[float, int]:

@@ -171,8 +171,10 @@ int crh_search_finish(crh_index *h, void *stream);
 
 int crh_search_get_stats(crh_index *h, crh_search_stats *out);
 
-/* HIP-event timing of the dominant kernel (the corpus scan), recorded on the search stream around
- * each launch while enabled; totals since the last enable.  Measurement support for bench.py. */
+/* HIP-event timing of the dominant kernel (the corpus scan; behind the int8 copy: the pass, the third of that scan's three
+ * launches), recorded on the search stream around each launch while enabled; totals since the last enable.  enable = 2: behind
+ * the int8 copy the two events bracket all three launches of the scan (sample tiles, thresholds, pass) -- the span one launch
+ * covered in rounds 3-4.  Measurement support for bench.py. */
 int crh_index_set_profiling(crh_index *h, int enable);
 int crh_index_get_profile(crh_index *h, double *scan_ms_total, int64_t *scan_launches);
 
