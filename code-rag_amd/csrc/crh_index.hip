@@ -78,8 +78,10 @@ struct crh_index {
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
     int i8_sample = kI8SampleTiles;         // sample tiles behind the int8 scan's thresholds: 8192 halves the candidates of 4096 for 100 MB more
                                             // sample reads (-22 us per batch on one index, tools/sample_ab.py); CODERAG_HIP_I8_SAMPLE
-    int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay (its selection step costs more: 100 k
-                                            // encoder embeddings took 0.38 ms per batch against 0.18 ms); CODERAG_HIP_I8_MIN_ROWS
+    int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay on every kind of data: Gaussian rows gain
+                                            // from 100 k rows up (0.134 against 0.147 ms per batch; 0.285 / 0.360 at 1M), rows around one shared
+                                            // mean with isotropic noise -- the widest candidate sets -- only from ~1.5M (1M: 0.397 against 0.358;
+                                            // 2M: 0.554 / 0.597; profiles/r04_i8_crossover.txt); CODERAG_HIP_I8_MIN_ROWS
     int64_t cap_rows = 0, cap_tiles = 0, count = 0, alive_count = 0;
     // The validity mask of the last filter is kept while nothing it was built from has changed (rows, alive bits, codes: every
     // mutation bumps `mutations`): the reference's searchers send the same equality filter with query after query (project_name,
