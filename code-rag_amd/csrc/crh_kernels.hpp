@@ -1804,6 +1804,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long *
                 const u32x4 *xr = stage + (unsigned int)tid * pitch;
                 float acc = 0.0f;
                 if (F32) {
+#pragma unroll 4
                     for (int c = 0; c < cpr; ++c) {
                         const u32x4 pk = xr[c];
                         const float *qq = qv + 4 * c;
@@ -1818,6 +1819,7 @@ __global__ __launch_bounds__(256) void k_select_final(const unsigned long long *
                         acc = acc + p;
                     }
                 } else {
+#pragma unroll 4
                     for (int c = 0; c < cpr; ++c) {
                         const u32x4 pk = xr[c];
                         const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
