@@ -76,6 +76,7 @@ struct crh_index {
     int i8_cooldown = 0;      // ... for this many batches; then it gets ONE more try, and the next overflow rests it again)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
+    bool i8_sample_auto = true;             // (CODERAG_HIP_I8_SAMPLE set: that many tiles at every size)
     int i8_sample = kI8SampleTiles;         // sample tiles behind the int8 scan's thresholds: 8192 halves the candidates of 4096 for 100 MB more
                                             // sample reads (-22 us per batch on one index, tools/sample_ab.py); CODERAG_HIP_I8_SAMPLE
     int64_t i8_min_rows = 1000000;          // below this the pass is too short for the copy to pay on every kind of data: Gaussian rows gain
@@ -466,7 +467,13 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
 
     if (via_i8) {
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ntiles, kI8Waves), h->cu_count));
-        const int G8 = (int)std::min<int64_t>(h->seed_tiles == 4096 ? h->i8_sample : h->seed_tiles, ntiles);
+        // The sample is read twice (its own launch, then the pass) and buys the thresholds: its cost grows with G, the candidates
+        // it leaves with 1 / G -- the best G goes with the square root of the corpus.  8192 tiles were tuned at 10M rows (2.6 % of
+        // them); the same 8192 are 26 % of a 1M-row corpus (profiles/r04_i8_crossover.txt).  An explicit sample size is kept.
+        int64_t g_auto = h->i8_sample;
+        if (h->seed_tiles == 4096 && h->i8_sample_auto)
+            g_auto = std::max<int64_t>(1024, std::min<int64_t>(h->i8_sample, (int64_t)(h->i8_sample * std::sqrt((double)ntiles / 312500.0))));
+        const int G8 = (int)std::min<int64_t>(h->seed_tiles == 4096 ? g_auto : h->seed_tiles, ntiles);
         const int S8 = (int)std::max<int64_t>(1, ntiles / G8);
         // what separates a row's canonical score from the exact dot of the QUANTISED-FROM rows and the canonical query: the two f32
         // summation orders only -- the copy of an f32 store is quantised from its f32 master, not from the bf16 tiles
@@ -714,7 +721,10 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         h->i8 = h->fused_scan && !(e8 && e8[0] == '0');
         if (h->i8) h->qcap = 131072;   // ~21 k candidates per query and 10M Gaussian rows behind the int8 scan (37 k with 4096 sample tiles)
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
-        if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
+        if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) {
+            h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
+            h->i8_sample_auto = false;
+        }
         if (const char *er = getenv("CODERAG_HIP_ROWMAJOR")) h->want_xrow = er[0] != '0';
     }
     h->dtype = dtype;
