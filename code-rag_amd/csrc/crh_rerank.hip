@@ -53,6 +53,28 @@ __global__ void k_gather_bytes(int64_t n, const int64_t *__restrict__ rows, int6
     out[i] = (rows[c] >= 0 && r >= 0 && r < n_local) ? col[r * width + b] : (uint8_t)0;
 }
 
+// all side columns of a candidate table in one launch: out = [6 int32 columns][n], then [n][CRH_RR_NAME_BYTES] name bytes
+// (as 32-bit words); thread per output word
+__global__ void k_gather_packed(int64_t n, const int64_t *__restrict__ rows, int64_t row_base, int64_t n_local, crh_rerank_columns cols,
+                                int32_t *__restrict__ out)
+{
+    constexpr int NW = CRH_RR_NAME_BYTES / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (6 + NW)) return;
+    if (i < 6 * n) {
+        const int c = (int)(i / n);
+        const int64_t j = i - (int64_t)c * n;
+        const int64_t r = rows[j] - row_base;
+        const int32_t *col = c == 0 ? cols.content_len : c == 1 ? cols.degree : c == 2 ? cols.file_code : c == 3 ? cols.key_code : c == 4 ? cols.node_code : cols.name_len;
+        out[i] = (rows[j] >= 0 && r >= 0 && r < n_local) ? col[r] : 0;
+    } else {
+        const int64_t w = i - 6 * n, j = w / NW;
+        const int word = (int)(w - j * NW);
+        const int64_t r = rows[j] - row_base;
+        out[i] = (rows[j] >= 0 && r >= 0 && r < n_local) ? reinterpret_cast<const int32_t *>(cols.name)[r * NW + word] : 0;
+    }
+}
+
 struct RerankArgs {
     const float *scores;
     const int64_t *rows;
@@ -246,6 +268,17 @@ __global__ __launch_bounds__(256) void k_rerank_vector(RerankArgs a)
     if (mine) atomicAdd(&total, mine);
     __syncthreads();
     if (tid == 0) a.out_count[q] = need_host ? -1 : total;
+    // the slots behind the survivors: (-1, 0, 0.., 0) -- written here, so that no caller has to clear the outputs before a call
+    for (int slot = total + tid; slot < a.max_total; slot += blockDim.x) {
+        const size_t o = (size_t)q * a.max_total + slot;
+        a.out_index[o] = -1;
+        a.out_score[o] = 0.0;
+        a.out_signals[o * 4 + 0] = 0.0;
+        a.out_signals[o * 4 + 1] = 0.0;
+        a.out_signals[o * 4 + 2] = 0.0;
+        a.out_signals[o * 4 + 3] = 0.0;
+        a.out_flags[o] = 0;
+    }
 }
 
 }  // namespace
@@ -263,6 +296,22 @@ int crh_gather_rows_i32(int64_t n, const int64_t *rows_dev, int64_t row_base, in
     if (!rows_dev || !out_dev || (n_local > 0 && !col_dev)) return fail(CRH_E_INVALID, "gather: NULL pointer");
     hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, rows_dev, row_base,
                        n_local, col_dev, fill, out_dev);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_gather_rerank_columns(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const crh_rerank_columns *cols,
+                              int32_t *out_packed_dev, void *stream)
+{
+    if (n < 0 || n_local < 0) return fail(CRH_E_INVALID, "gather: negative size");
+    if (n == 0) return CRH_OK;
+    if (!rows_dev || !out_packed_dev || !cols) return fail(CRH_E_INVALID, "gather: NULL pointer");
+    if (n_local > 0 && (!cols->content_len || !cols->degree || !cols->file_code || !cols->key_code || !cols->node_code || !cols->name_len || !cols->name))
+        return fail(CRH_E_INVALID, "gather: NULL column");
+    if ((reinterpret_cast<uintptr_t>(cols->name) & 3u) != 0) return fail(CRH_E_INVALID, "gather: the name column must be 4-byte aligned");
+    const int64_t words = n * (6 + CRH_RR_NAME_BYTES / 4);
+    hipLaunchKernelGGL(k_gather_packed, dim3((unsigned)ceil_div(words, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, rows_dev, row_base,
+                       n_local, *cols, out_packed_dev);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

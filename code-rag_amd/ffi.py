@@ -31,7 +31,7 @@ EXPORTS = (
     "crh_index_set_nomination", "crh_index_get_nomination",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
     "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
-    "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_rerank_vector",
+    "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_gather_rerank_columns", "crh_rerank_vector",
     "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed", "crh_encoder_finish",
 )
 # exported by lib/libcoderag_hip_debug.so only (same sources built with -DCRH_ENABLE_DEBUG; tools/ and kernel tests)
@@ -156,6 +156,7 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_encoder_finish.argtypes = [vp]
     L.crh_gather_rows_i32.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
     L.crh_gather_rows_bytes.argtypes = [i64, vp, i64, i64, vp, i32, vp, vp]
+    L.crh_gather_rerank_columns.argtypes = [i64, vp, i64, i64, vp, vp, vp]
     L.crh_rerank_vector.argtypes = [i32, i32, vp, vp, C.POINTER(RerankColumns), vp, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     if debug or hasattr(L, "crh_debug_gemm_variant"):   # (CODERAG_HIP_LIB may point a tool's whole run at the debug build)
         debug = True

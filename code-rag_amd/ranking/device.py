@@ -180,15 +180,12 @@ class SideColumns:
         buf = t.empty((n * (len(self.INT_COLS) + words),), dtype=t.int32, device=self.device)
         out = PackedColumns()
         out.packed = buf
-        L = ffi.lib()
+        # one launch for the seven columns (crh_gather_rerank_columns; six launches of crh_gather_rows_* until round 4)
+        cc = ffi.RerankColumns(*(dev[c].data_ptr() for c in (*self.INT_COLS, "name")))
+        ffi.check(ffi.lib().crh_gather_rerank_columns(n, rows_dev.data_ptr(), row_base, self.rows, C.byref(cc), buf.data_ptr(), stream))
         for i, c in enumerate(self.INT_COLS):
-            o = buf[i * n:(i + 1) * n]
-            ffi.check(L.crh_gather_rows_i32(n, rows_dev.data_ptr(), row_base, self.rows, dev[c].data_ptr(), 0, o.data_ptr(), stream))
-            out[c] = o
-        o = buf[len(self.INT_COLS) * n:].view(t.uint8).view(n, ffi.RR_NAME_BYTES)
-        ffi.check(L.crh_gather_rows_bytes(n, rows_dev.data_ptr(), row_base, self.rows, dev["name"].data_ptr(), ffi.RR_NAME_BYTES,
-                                          o.data_ptr(), stream))
-        out["name"] = o
+            out[c] = buf[i * n:(i + 1) * n]
+        out["name"] = buf[len(self.INT_COLS) * n:].view(t.uint8).view(n, ffi.RR_NAME_BYTES)
         return out
 
 
@@ -254,9 +251,16 @@ class DeviceReranker:
 
     def rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None) -> RerankOutput:
         with self._lock:
-            return self._rank(scores_dev, rows_dev, cols, plans, stream)
+            return self._rank(scores_dev, rows_dev, cols, plans, stream)()
 
-    def _rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None) -> RerankOutput:
+    def rank_async(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None):
+        """:meth:`rank` in two halves: everything is enqueued on ``stream`` (the copy back included) and a callable is returned
+        that waits for it and builds the :class:`RerankOutput`.  Between the two the caller may enqueue more work on the stream
+        -- a serving loop enqueues the next search there, so that the device has something to do while the host collects this
+        batch.  ONE call may be outstanding per reranker (its device and pinned buffers are reused), from one thread."""
+        return self._rank(scores_dev, rows_dev, cols, plans, stream)
+
+    def _rank(self, scores_dev, rows_dev, cols: dict[str, Any], plans, stream: int | None = None):
         t = self._torch
         ffi.use_device(self.device.index)
         stream = ffi.current_stream(self.device) if stream is None else stream
@@ -265,7 +269,7 @@ class DeviceReranker:
             raise ValueError(f"{len(plans)} plans for {nq} candidate lists")
         mt = self.config.max_total
         # ONE device buffer and ONE pinned host mirror hold every output (f64 parts first: alignment), cached per shape; the
-        # packed queries go up from pinned memory: one H2D, two fills, the kernel, one D2H and one wait per call
+        # packed queries go up from pinned memory: one H2D, the kernel, one D2H and one wait per call
         # (five allocations + fills and five synchronising .cpu() copies were 0.3 ms of a 0.43 ms call)
         n = nq * mt
         nbytes = 8 * n + 32 * n + 4 * n + 4 * n + 4 * nq
@@ -289,9 +293,7 @@ class DeviceReranker:
         on = contextlib.nullcontext() if stream == cur.cuda_stream else t.cuda.stream(t.cuda.ExternalStream(stream, device=self.device))
         with on:
             qhost.numpy()[:] = packed       # (every call ends synchronised: the pinned buffers are free again)
-            qdev.copy_(qhost, non_blocking=True)
-            dbuf.zero_()
-            o_idx.fill_(-1)
+            qdev.copy_(qhost, non_blocking=True)     # (the kernel pads the slots behind a query's survivors itself: no fills here)
             cc = ffi.RerankColumns(*(cols[c].data_ptr() for c in ("content_len", "degree", "file_code", "key_code", "node_code", "name_len", "name")))
             ffi._typed(scores_dev, "float32", "scores")
             ffi._typed(rows_dev, "int64", "rows")
@@ -301,11 +303,14 @@ class DeviceReranker:
             hbuf.copy_(dbuf, non_blocking=True)
             done = t.cuda.Event()
             done.record()
+
+        def collect() -> RerankOutput:
             done.synchronize()
-        h = hbuf.numpy()
-        return RerankOutput(h[40 * n:44 * n].view(np.int32).reshape(nq, mt).copy(), h[:8 * n].view(np.float64).reshape(nq, mt).copy(),
-                            h[8 * n:40 * n].view(np.float64).reshape(nq, mt, 4).copy(), h[48 * n:].view(np.int32).copy(),
-                            h[44 * n:48 * n].view(np.int32).reshape(nq, mt).astype(bool))
+            h = hbuf.numpy()
+            return RerankOutput(h[40 * n:44 * n].view(np.int32).reshape(nq, mt).copy(), h[:8 * n].view(np.float64).reshape(nq, mt).copy(),
+                                h[8 * n:40 * n].view(np.float64).reshape(nq, mt, 4).copy(), h[48 * n:].view(np.int32).copy(),
+                                h[44 * n:48 * n].view(np.int32).reshape(nq, mt).astype(bool))
+        return collect
 
     @staticmethod
     def materialise(out: RerankOutput, q: int, hits: Sequence[dict[str, Any]]) -> list[RankedResult]:

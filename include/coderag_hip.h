@@ -259,13 +259,20 @@ int crh_gather_rows_i32(int64_t n, const int64_t *rows_dev, int64_t row_base, in
                         int32_t *out_dev, void *stream);
 int crh_gather_rows_bytes(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const uint8_t *col_dev, int width,
                           uint8_t *out_dev, void *stream);
+/* The seven of them in ONE launch: `cols` holds this shard's PER-ROW columns (device pointers; `name` 4-byte aligned), the output
+ * is one int32 buffer -- the six integer columns in the order of the struct, n entries each, then n x CRH_RR_NAME_BYTES name
+ * bytes -- i.e. the per-candidate arrays crh_rerank_vector takes are views of it, and a row-sharded caller completes the
+ * table of a merged candidate list with one all-reduce(sum) over it (rows of other shards give zeros). */
+int crh_gather_rerank_columns(int64_t n, const int64_t *rows_dev, int64_t row_base, int64_t n_local, const crh_rerank_columns *cols,
+                              int32_t *out_packed_dev, void *stream);
 
 /* Re-rank nq candidate lists of k vector hits (scores/rows as crh_search or crh_merge_topk return them; rows < 0 = padding).
  * The centrality table of a query holds the first `centrality_top` named hits, as QueryEngine._get_centrality_scores builds
  * it for a query without graph results (query/engine.py:348-377).  Outputs, per query, in final order: index into the
  * candidate list, final score, the four signals (vector_similarity, query_entity_match, centrality, code_quality), flag
  * bit 0 = "hybrid" (entries sharing a merge key were fused); out_count[q] = survivors (<= max_total), or -1 when the host
- * must rank this query (too many entities, a truncated name).  `queries_dev` is a device copy of nq crh_rerank_query. */
+ * must rank this query (too many entities, a truncated name); the slots behind a query's survivors are written as (-1, 0, ...):
+ * the outputs need no clearing before a call.  `queries_dev` is a device copy of nq crh_rerank_query. */
 int crh_rerank_vector(int nq, int k, const float *scores_dev, const int64_t *rows_dev, const crh_rerank_columns *cols,
                       const crh_rerank_query *queries_dev, double entity_match_bonus, int max_per_file, int max_total,
                       int centrality_top, int32_t *out_index_dev, double *out_score_dev, double *out_signals_dev,
