@@ -50,16 +50,17 @@ if three:
         v = (a[:, :, i] - t0) / 100.0
         print(f"  {i} {n:12s} {v.min(axis=1).mean():9.1f} {np.median(v, axis=1).mean():9.1f} {v.max(axis=1).mean():9.1f}   (us after the first workgroup's entry: min / median / max)")
     a[:, :, 1:5] = a[:, :, :1]                       # (stamps 1..4 belong to the one-launch scans only)
-print("stamp (us after the first workgroup's entry): min / median / max over workgroups, mean over runs")
-for i in range(7):
-    v = (a[:, :, i] - t0) / 100.0
-    print(f"  {i} {(['entry'] + names)[i]:12s} {v.min(axis=1).mean():9.1f} {np.median(v, axis=1).mean():9.1f} {v.max(axis=1).mean():9.1f}")
-d = np.diff(a[:, :, :7], axis=2) / 100.0
-print("phase durations (us): median over workgroups / max, mean over runs")
-for i, n in enumerate(names):
-    print(f"  {n:12s} {np.median(d[:, :, i], axis=1).mean():9.1f} {d[:, :, i].max(axis=1).mean():9.1f}")
-tauwg = d[:, :B, 3]; rest = d[:, B:, 3]
-print(f"threshold phase: workgroups 0..{B-1} (one query each) median {np.median(tauwg):.1f} us, the others {np.median(rest):.1f} us")
+if not three:
+    print("stamp (us after the first workgroup's entry): min / median / max over workgroups, mean over runs")
+    for i in range(7):
+        v = (a[:, :, i] - t0) / 100.0
+        print(f"  {i} {(['entry'] + names)[i]:12s} {v.min(axis=1).mean():9.1f} {np.median(v, axis=1).mean():9.1f} {v.max(axis=1).mean():9.1f}")
+    d = np.diff(a[:, :, :7], axis=2) / 100.0
+    print("phase durations (us): median over workgroups / max, mean over runs")
+    for i, n in enumerate(names):
+        print(f"  {n:12s} {np.median(d[:, :, i], axis=1).mean():9.1f} {d[:, :, i].max(axis=1).mean():9.1f}")
+    tauwg = d[:, :B, 3]; rest = d[:, B:, 3]
+    print(f"threshold phase: workgroups 0..{B-1} (one query each) median {np.median(tauwg):.1f} us, the others {np.median(rest):.1f} us")
 w = (np.stack(wacc) - t0[:, :, None]) / 100.0            # [runs, wg, wave]: end of each wave's main loop
 wa = np.stack(wacc)
 if (wa[:, :B, 8:13] > 0).all():      # k_scan_i8: sub-stamps of the threshold launch's workgroups 0..63 (slots 8..12)
