@@ -46,7 +46,10 @@ def test_eight_ranks_strong_scaling_with_the_config5_and_embed_collectives():
     # rank travel in one all-gather (here the rehearsal's stand-ins, -1 - rank and rank, in rank order)
     assert rec["per_rank_nomination"] == [-1 - r for r in range(8)] and rec["per_rank_fallback_used"] == list(range(8))
     assert rec["rows_per_gpu"] == 10000 and rec["scaling"] == "strong" and len(rec["per_rank_step_ms"]) == 8
-    assert [d["rank"] for d in rec["per_rank_device"]] == list(range(8)) and sorted(d["local_rank"] for d in rec["per_rank_device"]) == list(range(8))
+    assert sorted(rec["per_rank_local_rank"]) == list(range(8))
+    assert len(lines[0]) < 4096
+    full = json.load(open(os.path.join(ROOT, rec["detail"])))             # the sidecar holds the full per-rank device records
+    assert [d["rank"] for d in full["per_rank_device"]] == list(range(8))
 
 
 def test_world_size_mismatch_is_refused():
@@ -59,3 +62,54 @@ def test_parent_of_a_self_launch_never_imports_torch():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[:src.index("def rehearse")]
     assert "import torch" not in head.replace("torch.distributed.run", "")
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_stdout_line_of_a_full_record_stays_under_4_kib_and_is_strict_json(tmp_path):
+    """Round 4's driver record went unparsed: the one line had grown to 22 KB and the driver keeps a bounded tail.  The line is
+    now distilled from the full record (which goes to a sidecar): here from round 4's committed full record, all legs present."""
+    bench = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default_v6.json")))
+    full["embed"]["roofline"]["frac"] = float("nan")                       # a NaN in a sub-record must not make the line non-strict
+    r, w = os.pipe()
+    bench.ROOT = str(tmp_path)                                            # sidecar into the test's directory
+    bench.emit(full, w)
+    os.close(w)
+    text = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert text.endswith("\n") and text.count("\n") == 1 and len(text.encode()) <= 4096
+
+    def refuse(c):
+        raise AssertionError(c)
+    line = json.loads(text, parse_constant=refuse)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert key in line, key
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "whole_step_frac", "bf16_scan"} <= set(roof)
+    assert roof["bf16_scan"]["algorithmic_bytes_per_launch"] == 10_000_000 * 768 * 2 and roof["algorithmic_bytes_per_launch"] == 10_000_000 * 772
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    for leg in bench.SHORT_LEGS:
+        assert line[leg]["value"] > 0, leg
+    assert line["embed"].get("frac") is None                               # the NaN became null / absent, not a bare NaN token
+    side = json.load(open(tmp_path / line["detail"]))
+    assert side["c2"]["parity"]["bf16_store"]["ids_bit_exact"] is True
+
+
+def test_write_all_finishes_a_short_write(monkeypatch):
+    bench = _bench_module()
+    got = []
+
+    def stingy(fd, data):
+        got.append(bytes(data[:7]))
+        return len(got[-1])
+    monkeypatch.setattr(bench.os, "write", stingy)
+    bench.write_all(1, b"x" * 100)
+    assert b"".join(got) == b"x" * 100

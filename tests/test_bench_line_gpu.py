@@ -19,7 +19,11 @@ def test_bench_prints_the_contract_line(gpu):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    assert len(lines[0].encode()) + 1 <= 4096, len(lines[0])          # round 4's 22 KB line was cut by the driver's bounded tail and went unparsed
+
+    def refuse(c):
+        raise AssertionError(f"non-strict JSON constant {c} in the line")
+    d = json.loads(lines[0], parse_constant=refuse)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -29,7 +33,17 @@ def test_bench_prints_the_contract_line(gpu):
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert d["parity"]["ids_bit_exact"] and d["parity"]["scores_bit_exact"], d["parity"]
-    for leg in ("filtered", "wide", "f32_store", "embed"):
+    assert roof["whole_step_frac"] > 0 and roof["kernel"] and roof["kernel_ms"] > 0 and roof["algorithmic_bytes_per_launch"] > 0
+    for leg in ("filtered", "wide", "f32_store", "embed"):          # one scalar + one fraction per leg in the line ...
         assert "error" not in d[leg], (leg, d[leg])
-        assert d[leg]["roofline"]["frac"] > 0
-    assert d["embed"]["cpu_baseline"]["value"] > 0
+        assert d[leg]["value"] > 0 and d[leg]["frac"] > 0
+        assert set(d[leg]) <= {"value", "unit", "ms", "frac", "bound", "step_frac", "ok"}, d[leg]
+    for leg in ("filtered", "wide", "f32_store"):
+        assert d[leg]["ok"] is True
+    # ... and the full records in the sidecar the line names
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and full["steps"] == 3
+    for leg in ("filtered", "wide", "f32_store", "embed"):
+        assert full[leg]["roofline"]["frac"] == pytest.approx(d[leg]["frac"], rel=1e-3)
+    assert full["embed"]["cpu_baseline"]["value"] > 0
+    assert full["search_stats"]["batches"] >= 3
