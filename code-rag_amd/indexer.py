@@ -174,13 +174,31 @@ class VectorIndexer:
             if not chunks:
                 logger.debug(f"No chunks generated for file: {file_path}")
                 return 0
-            vectors = await self.embedder.embed_with_progress([c.content for c in chunks], progress_callback=progress_callback)
-            await self.qdrant.upsert(collection=CollectionName.CODE_CHUNKS.value, ids=[str(uuid.uuid4()) for _ in chunks],
-                                     vectors=vectors, payloads=[c.to_payload() for c in chunks])
+            in_store = self._embed_in_store()
+            if in_store is not None:
+                # one process per shard: the store routes the rows, every rank embeds its own share, and an encoder failure on ONE
+                # rank is agreed by all inside the upsert (a rank that raised here, before the store's collectives, would leave
+                # the others waiting in them)
+                texts = [c.content for c in chunks]
+                await self.qdrant.upsert(CollectionName.CODE_CHUNKS.value, [str(uuid.uuid4()) for _ in chunks], None,
+                                         [c.to_payload() for c in chunks], texts=texts, embed=in_store)
+                if progress_callback:
+                    progress_callback(len(texts), len(texts))
+            else:
+                vectors = await self.embedder.embed_with_progress([c.content for c in chunks], progress_callback=progress_callback)
+                await self.qdrant.upsert(collection=CollectionName.CODE_CHUNKS.value, ids=[str(uuid.uuid4()) for _ in chunks],
+                                         vectors=vectors, payloads=[c.to_payload() for c in chunks])
             logger.info(f"Indexed {len(chunks)} chunks from {file_path}")
             return len(chunks)
         except Exception as e:
             raise IndexingError(f"Failed to index file {parsed_file.file_info.path}", stage="file_indexing", cause=e)
+
+    def _embed_in_store(self):
+        """The provider's synchronous embed callable when the store shards across PROCESSES (backend 'dist'), else None."""
+        backend = getattr(self.qdrant, "__dict__", {}).get("_shard_backend")       # (an instance attribute of HipVectorStore; other stores have none)
+        if not (isinstance(backend, str) and backend == "dist"):
+            return None
+        return getattr(getattr(self.embedder, "provider", None), "embed_texts_sync", None)
 
     async def index_files(self, parsed_files: list, progress_callback: Callable[[int, int], None] | None = None,
                           project_name: str | None = None) -> int:
@@ -231,7 +249,7 @@ class VectorIndexer:
                         await self.qdrant.delete(name, {"file_path": p})
             sync_embed = getattr(getattr(self.embedder, "provider", None), "embed_texts_sync", None)
             if embed_in_store is None:
-                embed_in_store = sync_embed is not None and getattr(self.qdrant, "_shard_backend", "local") == "dist"
+                embed_in_store = self._embed_in_store() is not None
             to_array = getattr(self.embedder, "embed_array", None)
 
             async def embed_and_store(chunks):

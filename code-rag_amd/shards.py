@@ -11,7 +11,8 @@ delete / count / match by filter, search, compact, save / load -- and spreads th
   (``append`` takes the rows of the owned shards only; ``exchange_bytes`` completes what only an owner holds).  Ids, the coded
   payload columns and the slot maps stay replicated.  The search is the path of ``sharded.ShardedIndex``: local scan with
   ``row_base``, ONE all-gather of the ``[scores | rows]`` records, merge on every rank.  Counts, matching rows and compaction maps travel in tensor
-  collectives as well (round 4; a compaction map is one entry per row); only the agreement on a FAILED append is a small host object.
+  collectives as well (round 4; a compaction map is one entry per row).  An append's outcome is agreed in ONE one-integer all-reduce;
+  only a FAILED append exchanges small host objects (the reason, and the rows that landed before the failure).
 
 Rows are dealt to the shards in blocks of ``block`` rows, round robin, so shards stay balanced under incremental upserts.
 A row's global id is ``shard * STRIDE + local row`` (``STRIDE`` = 2^32, a ``crh_index`` holds at most 2^31 rows): stable under
@@ -130,14 +131,19 @@ class ShardSet:
         self._next_block = int((self._next_block + blocks) % self.ns)
         return np.repeat(sh, self.block)[:n].astype(np.int32)
 
-    def append(self, vecs, codes, preprocessed: bool = False, stream: int = 0, shard: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
+    def append(self, vecs, codes, preprocessed: bool = False, stream: int = 0, shard: np.ndarray | None = None,
+               failure: BaseException | None = None) -> tuple[np.ndarray, np.ndarray]:
         """Append n rows.  ``vecs``: numpy [n, dim] or a CUDA tensor holding ALL n rows -- or, with ``shard`` (the routing of the
         n rows, from :meth:`route`), a dict {owned shard: its rows in order}: the form a rank uses when it has embedded only its
         own share.  ``codes``: numpy [n, cols] for all n rows, or None.  Returns (shard [n], local row [n]).
 
         Nothing is committed until every owned shard has the capacity; if a shard's append still fails, the rows the earlier
         shards took are tombstoned and :class:`AppendFailed` tells the caller where they sit.  Under backend "dist" the ranks
-        agree on the outcome before anyone returns."""
+        agree on the outcome before anyone returns (one one-integer all-reduce when all is well).
+
+        ``failure``: an error this process met while PREPARING its rows (its share of the texts would not embed): nothing is
+        appended here, but the call is still made so that every rank takes part in the same agreement and leaves the same way --
+        a rank that raised before this point would leave the others waiting in the collective."""
         per_shard = isinstance(vecs, dict)
         if per_shard and shard is None:
             raise ValueError("per-shard rows need the routing they were cut by")
@@ -153,8 +159,9 @@ class ShardSet:
                 local[sel] = self.rows[s] + np.arange(sel.size)
                 plan.append((s, sel, self.rows[s]))
         done: dict[int, tuple[int, int]] = {}
-        failure: BaseException | None = None
         try:
+            if failure is not None:
+                raise failure
             for s, sel, first in plan:                # capacity first, on every owned shard: a refusal here leaves nothing behind
                 if s in self.index and first + sel.size > self.index[s].capacity_rows:
                     self.index[s].reserve(max(first + int(sel.size), 2 * self.index[s].capacity_rows))
@@ -185,9 +192,10 @@ class ShardSet:
         except BaseException as e:  # noqa: BLE001 -- rolled back below, then re-raised
             failure = e
         if self.dist is not None:                     # one rank's failure is everybody's: the replicated bookkeeping must not part ways
-            outcomes = self._everyone(None if failure is None else repr(failure))
-            if failure is None and any(o is not None for o in outcomes):
-                failure = RuntimeError(f"append failed on another rank: {[o for o in outcomes if o is not None][0]}")
+            if self._sum_everyone(0 if failure is None else 1):
+                outcomes = self._everyone(None if failure is None else repr(failure))
+                if failure is None:
+                    failure = RuntimeError(f"append failed on another rank: {[o for o in outcomes if o is not None][0]}")
         if failure is not None:
             for s, (got, m) in done.items():          # the rows that did land: dead, and accounted for
                 self.index[s].tombstone(np.arange(got, got + m, dtype=np.int64))

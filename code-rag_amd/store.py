@@ -141,7 +141,7 @@ class _Collection:
             have, want = side.rows, self.shards.rows[s]
             if have < want:
                 slots = np.arange(have, want) if self.shards.ns == 1 else self.slot_of[s][have:want]
-                side.append([self.payloads.get(int(t)) for t in slots])
+                side.append([self.payloads.get(int(t)) if t >= 0 else {} for t in slots])      # (-1: a dead row without a slot)
                 if self._degrees is not None:
                     side.set_degrees(self._degrees)
         return self._side
@@ -254,15 +254,24 @@ class _Collection:
             codes = self.payloads.device_codes(self.keys, n0, n0 + n) if self.keys else None
             if lazy:
                 per_shard = {}
-                for sh in self.shards.owned:
-                    sel = np.flatnonzero(shard == sh)
-                    if sel.size:
-                        v = embed([texts[i] for i in sel])
-                        v = v if bool(getattr(v, "is_cuda", False)) else np.asarray(v, dtype=np.float32)
-                        if v.ndim != 2 or int(v.shape[0]) != sel.size or int(v.shape[1]) != self.shards.dim:
-                            raise ValueError(f"embed returned {tuple(v.shape)} for {sel.size} texts of dimension {self.shards.dim}")
-                        per_shard[sh] = v
+                embed_failure = None
+                try:
+                    for sh in self.shards.owned:
+                        sel = np.flatnonzero(shard == sh)
+                        if sel.size:
+                            v = embed([texts[i] for i in sel])
+                            v = v if bool(getattr(v, "is_cuda", False)) else np.asarray(v, dtype=np.float32)
+                            if v.ndim != 2 or int(v.shape[0]) != sel.size or int(v.shape[1]) != self.shards.dim:
+                                raise ValueError(f"embed returned {tuple(v.shape)} for {sel.size} texts of dimension {self.shards.dim}")
+                            per_shard[sh] = v
+                except Exception as e:  # noqa: BLE001 -- carried into the append's agreement (below), re-raised from there
+                    embed_failure = e
                 dev_rows = [v for v in per_shard.values() if not isinstance(v, np.ndarray)]
+                if embed_failure is not None:
+                    # one rank's encoder failed (a bad text, out of memory): the others are already on their way into the append's
+                    # agreement collective -- this rank joins it with its failure, so that everyone rolls back and raises together
+                    self.shards.append({}, codes, preprocessed, shard=shard, failure=embed_failure)
+                    raise embed_failure          # (not reached: append re-raises it)
                 if dev_rows:
                     import torch
                     per_shard = {sh: (v.contiguous() if v.dtype == torch.float32 else v.float().contiguous()) if not isinstance(v, np.ndarray) else v
@@ -289,6 +298,15 @@ class _Collection:
                     self.slot_of[sh] = np.concatenate([self.slot_of[sh], np.full((m,), -1, np.int64)])
             else:
                 raise RuntimeError("a one-shard collection cannot lose an append half-way") from e
+            # the orphans are dead on the device already: reclaim them now, so that no later state (a snapshot, the side columns of
+            # the re-rank) ever holds a row without a slot.  Every rank is here (the append agreed on the failure), so the
+            # compaction's collectives line up.  Should the compaction itself fail, the maps above keep the collection usable
+            # and save() tries again.
+            try:
+                self.compact()
+            except Exception as ce:  # noqa: BLE001
+                raise e.cause from ce
+            self.shards._next_block = saved_next              # nothing of the call is left: the next rows are routed as if it had not been made
             raise e.cause
         except Exception:
             self.payloads.truncate(n0)                        # nothing was stored: the tables go back to where they were
@@ -319,9 +337,16 @@ class _Collection:
             return [self.payloads.get(t) for t in slots]
         import json
         mine = set(self.shards.owned)
-        parts = [json.dumps(self.payloads.get(t), default=repr, ensure_ascii=False).encode("utf-8", "surrogatepass") if int(self.row_shard[t]) in mine else None
-                 for t in slots]
-        return [json.loads(b.decode("utf-8", "surrogatepass")) for b in self.shards.exchange_bytes(parts)]
+        # only the TEXT fields travel (everything else is replicated and keeps its Python type: tuples, None, numbers)
+        local = [self.payloads.get(t) for t in slots]
+        parts = [json.dumps({k: p[k] for k in TEXT_KEYS if isinstance(p.get(k), str)}, ensure_ascii=False).encode("utf-8", "surrogatepass")
+                 if int(self.row_shard[t]) in mine else None for t, p in zip(slots, local)]
+        out = []
+        for p, b in zip(local, self.shards.exchange_bytes(parts)):
+            p = dict(p)
+            p.update(json.loads(b.decode("utf-8", "surrogatepass")))
+            out.append(p)
+        return out
 
     def hits(self, slots, scores) -> list[dict[str, Any]]:
         """Hit dictionaries of a flat list of (slot, score) pairs, payloads fetched together."""
@@ -367,6 +392,8 @@ class _Collection:
         if keep.size != before:
             self.ids.compact(keep)
             self.payloads.compact(keep)
+        moved = any(bool((o2n < 0).any()) for o2n in maps.values())      # (rows without a slot -- a half-way append -- count as well)
+        if moved:
             for s, side in self._side.items():
                 side.select(np.flatnonzero(maps[s][: side.rows] >= 0))
             self.compactions += 1
@@ -379,6 +406,8 @@ class _Collection:
         target and renamed over it, so a crash mid-save leaves the previous snapshot intact."""
         import json
         import shutil
+        if any(bool((so < 0).any()) for so in self.slot_of):      # rows without a slot (a half-way append whose clean-up failed) never reach a snapshot
+            self.compact()
         tmp = directory.rstrip("/") + ".tmp"
         primary = self.shards.rank in (None, 0)
         if primary:
@@ -397,8 +426,11 @@ class _Collection:
             self.row_shard.tofile(os.path.join(tmp, "rows.shard.i32"))
             self.row_local.tofile(os.path.join(tmp, "rows.local.i64"))
             with open(os.path.join(tmp, "collection.json"), "w") as f:
-                json.dump({"name": self.name, "keys": list(self.keys), "format": 3, "slots": self.payloads.n, "shards": self.shards.ns,
-                           "shard_rows": list(self.shards.rows), "degrees": self._degrees}, f, default=repr)
+                # format 4: says where the payload tables are ("text_tables": "per_rank" = tables{rank}/ hold the text of that
+                # rank's rows only, written by one process per shard; "root" = one complete table)
+                json.dump({"name": self.name, "keys": list(self.keys), "format": 4, "slots": self.payloads.n, "shards": self.shards.ns,
+                           "shard_rows": list(self.shards.rows), "degrees": self._degrees,
+                           "text_tables": "per_rank" if self.partial else "root"}, f, default=repr)
         self.shards.barrier()
         if primary:
             shutil.rmtree(directory, ignore_errors=True)
@@ -416,7 +448,14 @@ class _Collection:
         self.shards.load(directory)
         n = int(meta["slots"])
         self.ids.load(directory, n)
-        self.payloads.load(os.path.join(directory, f"tables{self.shards.rank}") if self.partial else directory)
+        per_rank = os.path.join(directory, f"tables{self.shards.rank}") if self.partial else None
+        layout = meta.get("text_tables") or ("per_rank" if per_rank and os.path.isdir(per_rank) else "root")
+        if layout == "per_rank" and not self.partial:
+            raise ValueError(f"snapshot of {self.name} was written by one process per shard (payload text split over tables0..{int(meta.get('shards', 1)) - 1}/): "
+                             "load it with shard_backend='dist' on as many ranks")
+        # a complete table at the root (format <= 3 of a 'dist' store, or a snapshot of in-process shards) serves a per-rank
+        # store as well: it merely holds more text than this rank needs
+        self.payloads.load(per_rank if layout == "per_rank" else directory)
         self.row_shard = np.fromfile(os.path.join(directory, "rows.shard.i32"), np.int32)
         self.row_local = np.fromfile(os.path.join(directory, "rows.local.i64"), np.int64)
         if self.payloads.n != n or sum(self.shards.rows) != n or list(self.shards.rows) != [int(v) for v in meta["shard_rows"]]:
