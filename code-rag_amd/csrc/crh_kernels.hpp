@@ -1,4 +1,4 @@
-// crh_kernels.cuh -- device code of the HBM-resident cosine index (gfx950 / CDNA4 only).
+// crh_kernels.hpp -- device code of the HBM-resident cosine index (gfx950 / CDNA4 only).
 //
 // Replaces what runs inside the Qdrant server for the reference's
 // QdrantManager.upsert / .search (src/lattice/embeddings/client.py:115-157):

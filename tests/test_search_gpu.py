@@ -20,6 +20,22 @@ def _ffi():
     return ffi
 
 
+@pytest.fixture(params=["int8 copy from 0 rows", "product default"])
+def policy(request, monkeypatch):
+    """tests/conftest.py lets every index of the GPU tier nominate from its int8 copy (CODERAG_HIP_I8_MIN_ROWS=0) so that the
+    newest path sees every case.  A typical code-rag corpus is 10 k - 1 M chunks, where the PRODUCT's default is the one-launch
+    scan over the bf16 tiles: the core parity cases therefore run under both policies (round-4 review, item 2), and under the
+    product's the index must report a bf16-tile form."""
+    if request.param == "product default":
+        monkeypatch.delenv("CODERAG_HIP_I8_MIN_ROWS", raising=False)
+    return request.param
+
+
+def _policy_holds(idx, ffi, policy):
+    if policy == "product default":
+        assert idx.nomination() in (ffi.NOMINATE_BF16, ffi.NOMINATE_BF16_3), idx.nomination()
+
+
 def _corpus(n, seed, scale=True):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((n, D), dtype=np.float32)
@@ -39,13 +55,14 @@ def _check(idx, ffi, x, q, k, bf16, filters=None, alive=None, codes=None, ofilte
 
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("n,nq,k", [(1000, 3, 10), (33, 1, 10), (7, 2, 10), (4099, 64, 100), (2048, 5, 1)])
-def test_small_exact(gpu, bf16, n, nq, k):
+def test_small_exact(gpu, bf16, n, nq, k, policy):
     ffi = _ffi()
     x, q = _corpus(n, 1), _corpus(nq, 2)
     idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=max(64, n))
     first = idx.append(x)
     assert first == 0 and idx.count() == (n, n)
     _check(idx, ffi, x, q, k, bf16)
+    _policy_holds(idx, ffi, policy)
     idx.close()
 
 
@@ -67,7 +84,7 @@ def test_stored_rows_match_oracle_preprocess(gpu, bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
-def test_filters_and_tombstones(gpu, bf16):
+def test_filters_and_tombstones(gpu, bf16, policy):
     ffi = _ffi()
     n = 5000
     rng = np.random.default_rng(5)
@@ -94,7 +111,7 @@ def test_filters_and_tombstones(gpu, bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
-def test_medium_batch64_top100(gpu, bf16):
+def test_medium_batch64_top100(gpu, bf16, policy):
     ffi = _ffi()
     n = 150_000
     x, q = _corpus(n, 7, scale=False), _corpus(64, 8)
@@ -111,7 +128,7 @@ def test_medium_batch64_top100(gpu, bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
-def test_exact_ties_prefer_lower_row(gpu, bf16):
+def test_exact_ties_prefer_lower_row(gpu, bf16, policy):
     ffi = _ffi()
     base = _corpus(40, 9)
     x = np.concatenate([np.repeat(base[:1], 700, axis=0), base, np.repeat(base[1:2], 300, axis=0)])
@@ -124,7 +141,7 @@ def test_exact_ties_prefer_lower_row(gpu, bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
-def test_overflow_regrow_path(gpu, bf16):
+def test_overflow_regrow_path(gpu, bf16, policy):
     ffi = _ffi()
     n = 20_000
     x, q = _corpus(n, 10), _corpus(64, 11)
@@ -138,7 +155,7 @@ def test_overflow_regrow_path(gpu, bf16):
     idx.close()
 
 
-def test_multi_batch_row_base_and_reserve(gpu):
+def test_multi_batch_row_base_and_reserve(gpu, policy):
     ffi = _ffi()
     n = 3000
     x, q = _corpus(n, 12), _corpus(130, 13)
@@ -159,7 +176,7 @@ def test_multi_batch_row_base_and_reserve(gpu):
     idx.close()
 
 
-def test_clustered_near_ties(gpu):
+def test_clustered_near_ties(gpu, policy):
     """Scores packed closely around the k-th: the canonical re-score has to decide the order."""
     ffi = _ffi()
     rng = np.random.default_rng(14)
@@ -295,7 +312,7 @@ def test_c_abi_error_paths(gpu):
         idx.count()
 
 
-def test_short_batches_do_not_nominate_for_padding_columns(gpu):
+def test_short_batches_do_not_nominate_for_padding_columns(gpu, policy):
     """A batch of fewer than 64 queries pads the MFMA columns with zero vectors; those columns must nominate nothing
     (they once passed every row, which overflowed the candidate buffers and quadrupled the scan time)."""
     ffi = _ffi()
@@ -336,7 +353,7 @@ def test_clustered_corpus_with_near_duplicate_scores(gpu, bf16):
     idx.close()
 
 
-def test_randomised_configurations_against_the_oracle(gpu):
+def test_randomised_configurations_against_the_oracle(gpu, policy):
     """60 seeded random configurations -- width, store precision, row count (down to 1), query count (across the 64-query
     pass boundary and the 256-query one of the wide scan), k (beyond the row count too), tombstones, a payload filter, duplicated rows (exact ties), zero rows,
     a non-zero row_base, appends in several pieces -- each compared bit for bit with the oracle."""
@@ -597,7 +614,7 @@ def _same(s, r, es, er):
 
 
 @pytest.mark.parametrize("bf16", [True, False])
-def test_back_to_back_batches_each_keep_their_own_queries(gpu, bf16):
+def test_back_to_back_batches_each_keep_their_own_queries(gpu, bf16, policy):
     """Twelve batches of DIFFERENT queries (ragged sizes, two values of k) are enqueued without a host wait in between: the
     batches share one workspace (query images, thresholds, candidate lists) and only stream order keeps them apart; every
     batch must come back with its own answer."""
@@ -875,7 +892,7 @@ def test_65_to_128_queries_take_two_passes_over_the_int8_copy_instead_of_one_wid
     idx.close()
 
 
-def test_the_kept_filter_mask_follows_every_mutation(gpu):
+def test_the_kept_filter_mask_follows_every_mutation(gpu, policy):
     """The validity mask of the last filter is kept while nothing it was built from has changed (the reference's searchers repeat
     one equality filter query after query).  Every mutation -- append, tombstone by row and by filter, compaction, reserve -- and a
     change of filter or of stream must rebuild it: each search below is checked against the oracle on the state it should see."""
