@@ -271,6 +271,8 @@ def contract_line(out: dict) -> dict:
         ex = out.get("exchange_ms_device")
         if isinstance(ex, dict):
             line["exchange_ms_device"] = {k: _r(v, 5) for k, v in ex.items() if k != "what"}
+    if out.get("errors"):
+        line["errors"] = [str(e)[:120] for e in out["errors"]][:6]
     line["detail"] = DETAIL_NAME
     return line
 
@@ -323,7 +325,9 @@ def rehearse(args, json_fd) -> None:
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # (a rank that dies mid-run must take the others down in bounded time, not after gloo's default 30 minutes)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("CODERAG_BENCH_COLLECTIVE_TIMEOUT_S", "120"))))
     B, K = args.queries, args.k
     dev = torch.device("cpu")
     local, loc_s, loc_r, gathered, all_s, all_r = ffi.topk_exchange_buffers(torch, world, B, K, dev)
@@ -385,6 +389,7 @@ def rehearse(args, json_fd) -> None:
     # each rank's shard): [mode, fallback_used] per rank in one all-gather -- here a recognisable stand-in, -1 - rank / rank
     nom = torch.zeros((world, 2), dtype=torch.int64)
     dist.all_gather_into_tensor(nom.view(-1), torch.tensor([-1 - rank, rank], dtype=torch.int64))
+    errs = first_contact_errors(world, int(len(set(ranks.tolist()))), devices, None, None)   # (devices here: distinct local ranks)
     if rank == 0:
         out = {"metric": "launcher rehearsal (gloo, CPU): no device work, not a measurement", "value": None, "unit": None,
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) * 1e3 / max(1, args.steps),
@@ -394,10 +399,38 @@ def rehearse(args, json_fd) -> None:
                "exchange_layout_ok": bool(layout_ok), "per_rank_step_ms": [float(v) for v in per_rank.tolist()],
                "rows_per_gpu": n_local, "legs_rehearsed": legs_ok, "per_rank_device": devices,
                "per_rank_nomination": [int(v) for v in nom[:, 0].tolist()], "per_rank_fallback_used": [int(v) for v in nom[:, 1].tolist()]}
+        if errs:
+            out["errors"] = errs
         emit(out, json_fd)
     dist.destroy_process_group()
-    if not layout_ok or not all(legs_ok.values()):
-        raise SystemExit(f"rehearsal: exchange layout ok = {layout_ok}, legs = {legs_ok}")
+    if not layout_ok or not all(legs_ok.values()) or errs:
+        raise SystemExit(f"rehearsal: exchange layout ok = {layout_ok}, legs = {legs_ok}, first-contact checks = {errs}")
+
+
+def first_contact_errors(world, collective_ranks, per_rank_device, per_rank_nom, merge_ok, shared_gpu=False) -> list:
+    """What an N > 1 record must show before its number means anything: N distinct ranks took part in the collectives, no two of
+    them sat on the same GPU, every rank nominated its batches the way rank 0 did (a rank that fell back to the bf16 tiles
+    halves the job's rate without failing anything), and the merged list equals the sort of the gathered ones."""
+    errs = []
+    if collective_ranks != world:
+        errs.append(f"{collective_ranks} distinct ranks took part in the all-gather, --gpus {world}")
+    if per_rank_device and not shared_gpu:
+        seen = {}
+        for d in per_rank_device:
+            bus = (d or {}).get("pci_bus_id")
+            key = bus if bus is not None else ("local_rank", (d or {}).get("local_rank"))
+            if key in seen:
+                errs.append(f"ranks {seen[key]} and {(d or {}).get('rank')} report the same device ({key})")
+            seen[key] = (d or {}).get("rank")
+    if per_rank_nom:
+        for r, (mode, fb) in enumerate(per_rank_nom):
+            if mode != per_rank_nom[0][0]:
+                errs.append(f"rank {r} nominated its batches in mode {mode}, rank 0 in mode {per_rank_nom[0][0]}")
+            if fb & 6:
+                errs.append(f"rank {r} fell back during the timed steps (fallback bits {fb})")
+    if merge_ok is False:
+        errs.append("the merged top-k differs from the sort of the gathered lists")
+    return errs
 
 
 # ------------------------------------------------------------------------------------------------ the measurement
@@ -620,11 +653,13 @@ def run(args, json_fd) -> None:
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("CODERAG_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
         if args.backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
             dist = HostStagedCollectives(dist)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
     legs = set(ALL_LEGS if world == 1 else ("config5", "embed", "c2")) if args.legs is None else \
         set(x for x in args.legs.split(",") if x and x != "none")
     unknown = legs - set(ALL_LEGS)
@@ -716,7 +751,7 @@ def run(args, json_fd) -> None:
 
     # ---- what actually took part in the exchange (N>1): distinct ranks seen through a real all-gather, per-rank step times,
     # and the merged list against a sort of the gathered lists (score descending, lower global row first)
-    rccl_ranks, per_rank_ms, merge_ok, per_rank_device, per_rank_nom = None, None, None, None, None
+    rccl_ranks, per_rank_ms, merge_ok, per_rank_device, per_rank_nom, per_rank_exchange_ms = None, None, None, None, None, None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -727,6 +762,9 @@ def run(args, json_fd) -> None:
         pr = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(pr, torch.tensor([float(np.median(per_step))], dtype=torch.float64, device=dev))
         per_rank_ms = [float(v) for v in pr.tolist()]
+        px = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(px, torch.tensor([float(np.median(exchange))], dtype=torch.float64, device=dev))
+        per_rank_exchange_ms = [float(v) for v in px.tolist()]
         nomt = torch.zeros((dist.get_world_size(), 2), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(nomt.view(-1), torch.tensor([int(nom_mode), int(stats["fallback_used"])], dtype=torch.int64, device=dev))
         per_rank_nom = [[int(a), int(b)] for a, b in nomt.tolist()]
@@ -797,6 +835,7 @@ def run(args, json_fd) -> None:
         "roofline": roof,
         "step_ms_device": pct(per_step),
         "per_rank_step_ms_device": per_rank_ms,
+        "per_rank_exchange_ms_device": per_rank_exchange_ms,      # median of [all-gather + merge] per step, every rank's own clock
         "per_rank_device": per_rank_device,
         # (2 = every batch of that rank was nominated from its int8 copy; fallback bits: 1 buffers regrown, 2 a grid-wide wait timed out, 4 a batch went to the bf16 scan)
         "per_rank_nomination": [a for a, _ in per_rank_nom] if per_rank_nom else None,
@@ -810,6 +849,11 @@ def run(args, json_fd) -> None:
     }
     if args.backend == "gloo":
         out["rehearsal"] = "ranks share one GPU and the collectives are host-staged gloo: everything but RCCL itself; NOT a measurement"
+    # first contact with a real N-GPU node: what must hold for the line to mean "N GPUs", checked by every rank on the gathered
+    # records (so that all ranks leave the same way); the line still goes out, then the run exits non-zero
+    first_contact = first_contact_errors(world, rccl_ranks, per_rank_device, per_rank_nom, merge_ok, shared_gpu=args.share_gpu) if dist is not None else []
+    if first_contact:
+        out["errors"] = first_contact
     log("parity subsample checked" if parity else "parity subsample skipped")
 
     def leg(name, fn, *a, key=None):
@@ -983,6 +1027,10 @@ def run(args, json_fd) -> None:
         emit(out, json_fd)
     if dist is not None:
         dist.destroy_process_group()
+    if first_contact:
+        for e in first_contact:
+            log(f"N>1 CHECK FAILED: {e}")
+        raise SystemExit(3)
 
 
 # ------------------------------------------------------------------------------------------------ config 5

@@ -113,3 +113,54 @@ def test_write_all_finishes_a_short_write(monkeypatch):
     monkeypatch.setattr(bench.os, "write", stingy)
     bench.write_all(1, b"x" * 100)
     assert b"".join(got) == b"x" * 100
+
+
+def test_first_contact_checks_name_what_is_wrong_with_an_n_gpu_record():
+    """Round-4 review, item 6: the first real 8-GPU record must fail loudly when it is not what it claims -- fewer ranks in the
+    collectives than --gpus, two ranks on one GPU, a rank that nominated its batches differently from rank 0 or fell back."""
+    bench = _bench_module()
+    dev = [{"rank": r, "local_rank": r, "pci_bus_id": f"0000:{r:02x}:00.0"} for r in range(4)]
+    nom = [[2, 0]] * 4
+    assert bench.first_contact_errors(4, 4, dev, nom, True) == []
+    assert any("3 distinct ranks" in e for e in bench.first_contact_errors(4, 3, dev, nom, True))
+    twice = [dict(d) for d in dev]
+    twice[3]["pci_bus_id"] = twice[1]["pci_bus_id"]
+    assert any("ranks 1 and 3" in e and "same device" in e for e in bench.first_contact_errors(4, 4, twice, nom, True))
+    assert bench.first_contact_errors(4, 4, twice, nom, True, shared_gpu=True) == []          # (the one-GPU rehearsal shares by design)
+    assert any("rank 2 nominated" in e for e in bench.first_contact_errors(4, 4, dev, [[2, 0], [2, 0], [1, 0], [2, 0]], True))
+    assert any("rank 1 fell back" in e for e in bench.first_contact_errors(4, 4, dev, [[2, 0], [2, 4], [2, 0], [2, 0]], True))
+    assert bench.first_contact_errors(4, 4, dev, [[2, 1]] * 4, True) == []                   # (bit 0, buffers regrown once, is not a fallback)
+    assert any("merged top-k" in e for e in bench.first_contact_errors(4, 4, dev, nom, False))
+    no_bus = [{"rank": r, "local_rank": 0, "pci_bus_id": None} for r in range(2)]             # no bus ids: local ranks stand in
+    assert any("same device" in e for e in bench.first_contact_errors(2, 2, no_bus, None, None))
+
+
+def test_a_rank_that_dies_mid_run_takes_the_others_down_instead_of_hanging_them(tmp_path):
+    """Each rank is a fresh child process launched the way a launcher would (RANK / WORLD_SIZE / MASTER_* in the environment);
+    rank 1 is killed while the steps run; rank 0 must exit non-zero by itself, well inside the collective time-out."""
+    import signal
+    import socket
+    import time
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CODERAG_BENCH_COLLECTIVE_TIMEOUT_S="30")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "4096",
+                                       "--steps", "5000000", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        time.sleep(8.0)                                            # (torch import + rendezvous + some thousands of steps)
+        assert procs[0].poll() is None and procs[1].poll() is None, "the rehearsal ended before the kill"
+        procs[1].send_signal(signal.SIGKILL)
+        t0 = time.time()
+        out, err = procs[0].communicate(timeout=60)
+        assert procs[0].returncode not in (0, None), (procs[0].returncode, err[-500:])
+        assert time.time() - t0 < 45
+        assert out.strip() == ""                                   # no line that could be taken for a measurement
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
