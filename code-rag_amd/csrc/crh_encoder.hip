@@ -272,6 +272,120 @@ __global__ __launch_bounds__(256) void k_layernorm768_res(bf16_t *__restrict__ x
     }
 }
 
+// ------------------------------------------------------------------ LayerNorm folded into the GEMMs around it (round 5)
+//
+// The post-LN layer keeps its residual stream UN-normalised between kernels.  A producer GEMM (O-projection, FFN2; epilogue 5 of
+// the three tiled kernels) writes r = bf16(acc + bias + h), h being the previous LayerNorm's output worked out on the fly from ITS
+// un-normalised rows (h = fma(fma(r', rstd, nmr), gamma, beta'), beta' = beta + bias folded on the host), and per row and 32-column
+// slot the slot's mean and sum of squared deviations of the ROUNDED outputs; k_ln_finalize combines a row's 24 pairs into
+// (rstd, nmr = -mu rstd); the consumer GEMM (QKV, FFN1; epilogues 3 / 4) multiplies r by weights that carry the LayerNorm gain
+// and finishes the normalisation per element: y = fma(acc, rstd, fma(nmr, c_n, b'_n)).  Nothing reads or writes a [T, 768]
+// tensor just to normalise it (two such passes per layer before: 98 + 49 MB read, 2 x 98 MB written at 65 k tokens).
+//
+// The statistics are built the same way in all three GEMM kernels, so a token's bits do not depend on which kernel its batch
+// size selects: a lane holds, per row and slot, 8 outputs (two C^T fragments of 4 consecutive columns); it sums their deviations
+// from the first of them (one pass, nothing kept), and the four lanes that share the row are joined pairwise (xor 16, then xor
+// 32) by the equal-count update mean = (a + b) / 2, M2 = M2a + M2b + (a - b)^2 n / 2 -- symmetric in its operands, so both lanes
+// of a pair hold the same bits.
+struct LnAcc {
+    float s, sd, sdd;   // shift (the lane's first element), sum of (x - s), sum of (x - s)^2
+};
+__device__ __forceinline__ void ln_acc4(LnAcc &a, bool first, float x0, float x1, float x2, float x3)
+{
+    // (explicit fma chains: the file is compiled with -ffp-contract=off, and one instruction per element is what this costs)
+    if (first) {
+        a.s = x0;
+        const float d1 = x1 - x0, d2 = x2 - x0, d3 = x3 - x0;
+        a.sd = (d1 + d2) + d3;
+        a.sdd = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, d1 * d1));
+    } else {
+        const float d0 = x0 - a.s, d1 = x1 - a.s, d2 = x2 - a.s, d3 = x3 - a.s;
+        a.sd = a.sd + ((d0 + d1) + (d2 + d3));
+        a.sdd = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, __builtin_fmaf(d0, d0, a.sdd))));
+    }
+}
+__device__ __forceinline__ float2 ln_acc_done8(const LnAcc &a)   // 8 elements -> (mean, M2)
+{
+    const float md = a.sd * 0.125f;
+    return float2{a.s + md, fmaxf(a.sdd - a.sd * md, 0.f)};
+}
+__device__ __forceinline__ float2 ln_join(float2 a, float2 b, float half_n)   // two partials of n elements each; half_n = n / 2
+{
+    const float d = a.x - b.x;
+    return float2{0.5f * (a.x + b.x), (a.y + b.y) + (d * d) * half_n};
+}
+// own value and the value of lane l ^ 16 (l ^ 32), in an order that depends on the lane only: (a, b) -> the same pair in both lanes
+// of a couple (see join16 / join32 further down for the instruction)
+__device__ __forceinline__ void pair16(float x, float &a, float &b);
+__device__ __forceinline__ void pair32(float x, float &a, float &b);
+// (mean, M2) of 8 elements in each of the four lanes that share a row -> of the row's 32-column slot, in all four
+__device__ __forceinline__ float2 ln_join_row(float2 p)
+{
+    float am, bm, a2, b2;
+    pair16(p.x, am, bm);
+    pair16(p.y, a2, b2);
+    p = ln_join(float2{am, a2}, float2{bm, b2}, 4.0f);
+    pair32(p.x, am, bm);
+    pair32(p.y, a2, b2);
+    return ln_join(float2{am, a2}, float2{bm, b2}, 8.0f);
+}
+
+// A row's 24 (mean, M2) pairs of 32 columns each -> (rstd, -mu * rstd), slots combined in index order (equal counts: mu = mean of
+// the means, M2 = sum of the M2s + 32 * sum (mean_p - mu)^2).  One thread per row, its 192 bytes fetched as 12 independent
+// 16-byte loads; 64 rows per workgroup so that 65 k rows fill the chip (one thread per row in 256-row workgroups, loads behind
+// a loop of unknown length: 10.9 us per call).
+constexpr int kLnSlots = 24;
+__global__ __launch_bounds__(64) void k_ln_finalize(const float *__restrict__ partials, float *__restrict__ stats, int rows, float eps)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= rows) return;
+    const float4 *p4 = reinterpret_cast<const float4 *>(partials) + (size_t)m * (kLnSlots / 2);
+    float4 v[kLnSlots / 2];
+#pragma unroll
+    for (int i = 0; i < kLnSlots / 2; ++i) v[i] = p4[i];
+    float msum = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnSlots / 2; ++i) {
+        msum += v[i].x;
+        msum += v[i].z;
+    }
+    const float mu = msum / (float)kLnSlots;
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnSlots / 2; ++i) {
+        const float d0 = v[i].x - mu, d1 = v[i].z - mu;
+        m2 += v[i].y;
+        dev += d0 * d0;
+        m2 += v[i].w;
+        dev += d1 * d1;
+    }
+    const float var = (m2 + 32.0f * dev) / (float)(32 * kLnSlots);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<float2 *>(stats + 2 * (size_t)m) = float2{rstd, -mu * rstd};
+}
+
+// y = bf16(fma(fma(x, rstd, nmr), gamma, beta)): the LayerNorm output itself, from statistics already known -- what the LAST layer
+// of a folded forward needs (the pool reads normalised rows); in place when y == x.  One wave per row, 8-byte accesses.
+__global__ __launch_bounds__(256) void k_ln_apply768(const bf16_t *__restrict__ x, const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, bf16_t *__restrict__ y, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float2 st = *reinterpret_cast<const float2 *>(stats + 2 * (size_t)r);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = i * 256 + lane * 4;
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(x + (size_t)r * 768 + e);
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        u32x2 o;
+        o.x = pack2(__builtin_fmaf(__builtin_fmaf(bf2f(w.x & 0xffffu), st.x, st.y), g.x, b.x), __builtin_fmaf(__builtin_fmaf(bf2f(w.x >> 16), st.x, st.y), g.y, b.y));
+        o.y = pack2(__builtin_fmaf(__builtin_fmaf(bf2f(w.y & 0xffffu), st.x, st.y), g.z, b.z), __builtin_fmaf(__builtin_fmaf(bf2f(w.y >> 16), st.x, st.y), g.w, b.w));
+        *reinterpret_cast<u32x2 *>(y + (size_t)r * 768 + e) = o;
+    }
+}
+
 // ------------------------------------------------------------------ GEMM  C = epi(A . W^T + bias)
 
 constexpr int BM = 256, BN = 128, BK = 64, STAGES = 3, GEMM_WAVES = 8;
@@ -300,7 +414,9 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
                                                             const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                            bf16_t *__restrict__ C, int M, int N, int K)
+                                                            bf16_t *__restrict__ C, int M, int N, int K,
+                                                            const float *__restrict__ aux0 = nullptr, const float *__restrict__ rstats = nullptr,
+                                                            float *__restrict__ partials = nullptr)
 {
     constexpr int kStage = (BM + BN) * BK * 2;  // bytes per stage: A tile (256 rows) then W tile (128 rows)
     constexpr int kPieces = (BM + BN) / 8;      // 1-KiB pieces per stage (8 rows each): 32 of A, 16 of W
@@ -506,7 +622,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 64 + nt * 16 + 4 * g);
         u32x2 rv[4][4];
-        if (EPI == 2) {
+        if (EPI == 2 || EPI == 5) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -516,35 +632,73 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_gemm_nt(const bf16_t *__res
                     rv[nt][mt] = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n0 + wn * 64 + nt * 16 + 4 * g);
                 }
         }
+        // EPI 3 / 4 ("LN in", crh_gemm256.hpp): per-row (rstd, -mu rstd) of the A rows and the column sums of the gain-scaled weights
+        float2 st[4];
+        float4 cv[4];
+        const bool res_ln = EPI == 5 && rstats != nullptr;   // epilogue 5: the residual is normalised on the fly (cv = the gain)
+        if (EPI == 3 || EPI == 4 || res_ln) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int m = m0 + wm * 64 + mt * 16 + c16;
+                m = m < M ? m : M - 1;
+                st[mt] = *reinterpret_cast<const float2 *>(rstats + 2 * (size_t)m);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4 *>(aux0 + n0 + wn * 64 + nt * 16 + 4 * g);
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int mh = 0; mh < 2; ++mh) {
+                const int mt = half * 2 + mh;
+                LnAcc la[2];   // EPI 5: the row's two 32-column slots of this wave
 #pragma unroll
-                for (int mh = 0; mh < 2; ++mh) {
-                    const int mt = half * 2 + mh;
+                for (int nt = 0; nt < 4; ++nt) {
                     float v0 = acc[nt][mt][0] + bv[nt].x, v1 = acc[nt][mt][1] + bv[nt].y, v2 = acc[nt][mt][2] + bv[nt].z,
                           v3 = acc[nt][mt][3] + bv[nt].w;
-                    if (EPI == 1) {
+                    if (EPI == 3 || EPI == 4) {
+                        v0 = __builtin_fmaf(acc[nt][mt][0], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].x, bv[nt].x));
+                        v1 = __builtin_fmaf(acc[nt][mt][1], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].y, bv[nt].y));
+                        v2 = __builtin_fmaf(acc[nt][mt][2], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].z, bv[nt].z));
+                        v3 = __builtin_fmaf(acc[nt][mt][3], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].w, bv[nt].w));
+                    }
+                    if (EPI == 1 || EPI == 4) {
                         const f32x2_t ga = gelu_erf2(f32x2_t{v0, v1}), gb = gelu_erf2(f32x2_t{v2, v3});
                         v0 = ga.x;
                         v1 = ga.y;
                         v2 = gb.x;
                         v3 = gb.y;
                     }
-                    if (EPI == 2) {
-                        v0 += bf2f(rv[nt][mt].x & 0xffffu);
-                        v1 += bf2f(rv[nt][mt].x >> 16);
-                        v2 += bf2f(rv[nt][mt].y & 0xffffu);
-                        v3 += bf2f(rv[nt][mt].y >> 16);
+                    if (EPI == 2 || EPI == 5) {
+                        const float h0 = bf2f(rv[nt][mt].x & 0xffffu), h1 = bf2f(rv[nt][mt].x >> 16), h2 = bf2f(rv[nt][mt].y & 0xffffu),
+                                    h3 = bf2f(rv[nt][mt].y >> 16);
+                        if (res_ln) {
+                            v0 = __builtin_fmaf(__builtin_fmaf(h0, st[mt].x, st[mt].y), cv[nt].x, v0);
+                            v1 = __builtin_fmaf(__builtin_fmaf(h1, st[mt].x, st[mt].y), cv[nt].y, v1);
+                            v2 = __builtin_fmaf(__builtin_fmaf(h2, st[mt].x, st[mt].y), cv[nt].z, v2);
+                            v3 = __builtin_fmaf(__builtin_fmaf(h3, st[mt].x, st[mt].y), cv[nt].w, v3);
+                        } else {
+                            v0 += h0;
+                            v1 += h1;
+                            v2 += h2;
+                            v3 += h3;
+                        }
                     }
                     u32x2 o;
                     o.x = pack2(v0, v1);
                     o.y = pack2(v2, v3);
+                    if (EPI == 5) ln_acc4(la[nt >> 1], (nt & 1) == 0, bf2f(o.x & 0xffffu), bf2f(o.x >> 16), bf2f(o.y & 0xffffu), bf2f(o.y >> 16));
                     const int row = mh * 16 + c16;           // row of the 32-row image
                     const int chunk = nt * 2 + (g >> 1);     // 16-byte chunk of the 128-byte row holding cols nt*16 + 4g ..
                     *reinterpret_cast<u32x2 *>(cimg + row * 128 + ((chunk ^ (row & 7)) << 4) + (g & 1) * 8) = o;
                 }
+                if (EPI == 5) {
+                    const float2 p0 = ln_join_row(ln_acc_done8(la[0])), p1 = ln_join_row(ln_acc_done8(la[1]));
+                    const int m = m0 + wm * 64 + mt * 16 + c16;
+                    if (g == 0 && m < M)
+                        *reinterpret_cast<float4 *>(partials + ((size_t)m * (N >> 5) + ((n0 >> 5) + wn * 2)) * 2) = float4{p0.x, p0.y, p1.x, p1.y};
+                }
+            }
             // (same wave wrote and reads: the compiler's lgkmcnt wait orders the LDS accesses; no barrier needed)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -593,11 +747,37 @@ __device__ __forceinline__ float join32(float x)
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {lo, lo}, b = {hi, hi}
     return SUM ? a + b : fmaxf(a, b);
 }
+__device__ __forceinline__ void pair16(float x, float &a, float &b)
+{
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = the even 16-lane row's value, b = the odd one's
+}
+__device__ __forceinline__ void pair32(float x, float &a, float &b)
+{
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = the lower half's value, b = the upper half's
+}
 #else
 template <bool SUM>
 __device__ __forceinline__ float join16(float x) { const float y = __shfl_xor(x, 16); return SUM ? x + y : fmaxf(x, y); }
 template <bool SUM>
 __device__ __forceinline__ float join32(float x) { const float y = __shfl_xor(x, 32); return SUM ? x + y : fmaxf(x, y); }
+__device__ __forceinline__ void pair16(float x, float &a, float &b)
+{
+    const float y = __shfl_xor(x, 16);
+    const bool odd = (threadIdx.x >> 4) & 1;
+    a = odd ? y : x;
+    b = odd ? x : y;
+}
+__device__ __forceinline__ void pair32(float x, float &a, float &b)
+{
+    const float y = __shfl_xor(x, 32);
+    const bool hi = (threadIdx.x >> 5) & 1;
+    a = hi ? y : x;
+    b = hi ? x : y;
+}
 #endif
 
 // grid = (H, B), block = NW*64.  qkv bf16 [B*L][3*H*64] (q | k | v thirds, head-major inside a third); out bf16 [B*L][H*64].
@@ -841,7 +1021,9 @@ __global__ __launch_bounds__(256) void k_pool(const bf16_t *__restrict__ tok, co
 // the size -- LDS-DMA moves 8 full 128-byte rows per instruction.)  N % 64 == 0, K % 64 == 0.
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_mid(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ C, int M, int N, int K)
+                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ C, int M, int N, int K,
+                                                     const float *__restrict__ aux0 = nullptr, const float *__restrict__ rstats = nullptr,
+                                                     float *__restrict__ partials = nullptr)
 {
     constexpr int TM = 64, TN = 64, S = 4;
     constexpr int kStage = (TM + TN) * BK * 2;   // 16 KiB: A rows then W rows, 16 pieces of 1 KiB, 4 per wave
@@ -911,33 +1093,58 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(const bf16_t *__restrict__ 
         }
     }
     // a lane holds, per (nt, mt), the 4 consecutive n = n0 + wn*32 + nt*16 + 4g + {0..3} of row m = m0 + wm*32 + mt*16 + c16
+    const bool res_ln = EPI == 5 && rstats != nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 32 + nt * 16 + 4 * g;
-        const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wm * 32 + mt * 16 + c16;
+        const int mc = m < M ? m : M - 1;          // (rows past M compute on a valid row and store nothing: the row joins below need every lane)
+        float2 st = float2{1.f, 0.f};
+        if (EPI == 3 || EPI == 4 || res_ln) st = *reinterpret_cast<const float2 *>(rstats + 2 * (size_t)mc);
+        LnAcc la;      // EPI 5: the row's 32-column slot of this wave
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = m0 + wm * 32 + mt * 16 + c16;
-            if (m >= M) continue;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wn * 32 + nt * 16 + 4 * g;
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
             float o0 = acc[nt][mt][0] + b4.x, o1 = acc[nt][mt][1] + b4.y, o2 = acc[nt][mt][2] + b4.z, o3 = acc[nt][mt][3] + b4.w;
-            if (EPI == 1) {
+            if (EPI == 3 || EPI == 4) {      // "LN in" (crh_gemm256.hpp): the same two fma per element as the other tiled kernels
+                const float4 c4 = *reinterpret_cast<const float4 *>(aux0 + n);
+                o0 = __builtin_fmaf(acc[nt][mt][0], st.x, __builtin_fmaf(st.y, c4.x, b4.x));
+                o1 = __builtin_fmaf(acc[nt][mt][1], st.x, __builtin_fmaf(st.y, c4.y, b4.y));
+                o2 = __builtin_fmaf(acc[nt][mt][2], st.x, __builtin_fmaf(st.y, c4.z, b4.z));
+                o3 = __builtin_fmaf(acc[nt][mt][3], st.x, __builtin_fmaf(st.y, c4.w, b4.w));
+            }
+            if (EPI == 1 || EPI == 4) {
                 const f32x2_t ga = gelu_erf2(f32x2_t{o0, o1}), gb = gelu_erf2(f32x2_t{o2, o3});
                 o0 = ga.x;
                 o1 = ga.y;
                 o2 = gb.x;
                 o3 = gb.y;
             }
-            if (EPI == 2) {
-                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n);
-                o0 += bf2f(r2.x & 0xffffu);
-                o1 += bf2f(r2.x >> 16);
-                o2 += bf2f(r2.y & 0xffffu);
-                o3 += bf2f(r2.y >> 16);
+            if (EPI == 2 || EPI == 5) {
+                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(R + (size_t)mc * N + n);
+                const float h0 = bf2f(r2.x & 0xffffu), h1 = bf2f(r2.x >> 16), h2 = bf2f(r2.y & 0xffffu), h3 = bf2f(r2.y >> 16);
+                if (res_ln) {
+                    const float4 g4 = *reinterpret_cast<const float4 *>(aux0 + n);
+                    o0 = __builtin_fmaf(__builtin_fmaf(h0, st.x, st.y), g4.x, o0);
+                    o1 = __builtin_fmaf(__builtin_fmaf(h1, st.x, st.y), g4.y, o1);
+                    o2 = __builtin_fmaf(__builtin_fmaf(h2, st.x, st.y), g4.z, o2);
+                    o3 = __builtin_fmaf(__builtin_fmaf(h3, st.x, st.y), g4.w, o3);
+                } else {
+                    o0 += h0;
+                    o1 += h1;
+                    o2 += h2;
+                    o3 += h3;
+                }
             }
             u32x2 o;
             o.x = pack2(o0, o1);
             o.y = pack2(o2, o3);
-            *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
+            if (EPI == 5) ln_acc4(la, nt == 0, bf2f(o.x & 0xffffu), bf2f(o.x >> 16), bf2f(o.y & 0xffffu), bf2f(o.y >> 16));
+            if (m < M) *reinterpret_cast<u32x2 *>(C + (size_t)m * N + n) = o;
+        }
+        if (EPI == 5) {
+            const float2 p = ln_join_row(ln_acc_done8(la));
+            if (g == 0 && m < M) *reinterpret_cast<float2 *>(partials + ((size_t)m * (N >> 5) + ((n0 >> 5) + wn)) * 2) = p;
         }
     }
 }
@@ -974,11 +1181,12 @@ unsigned gemm_grid(int T, int N)
 }
 
 template <int EPI>
-int launch_mid(const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
+int launch_mid(const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st,
+               const float *aux0 = nullptr, const float *rstats = nullptr, float *partials = nullptr)
 {
     const int64_t tiles = crh::ceil_div(T, 64) * (N / 64);
     hipLaunchKernelGGL((k_gemm_mid<EPI>), dim3((unsigned)(crh::ceil_div(tiles, 8) * 8)), dim3(256), 0, st, (const bf16_t *)x, (const bf16_t *)w, bias,
-                       (const bf16_t *)res, (bf16_t *)y, T, N, K);
+                       (const bf16_t *)res, (bf16_t *)y, T, N, K, aux0, rstats, partials);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -1022,23 +1230,30 @@ unsigned gemm256_grid(int T, int N)
 {
     return xcd_grid(crh::ceil_div(T, g256::BM), N / g256::BN, crh::current_device_cus() / 8);
 }
-int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st)
+int launch_gemm256(int epi, const void *x, const void *w, const float *bias, const void *res, void *y, int T, int N, int K, hipStream_t st,
+                   const float *aux0 = nullptr, const float *rstats = nullptr, float *partials = nullptr)
 {
     static OncePerDevice once;
     if (once.need()) {
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<0>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(g256::k_gemm_pp<5>), hipFuncAttributeMaxDynamicSharedMemorySize, g256::kLds));
     }
     const dim3 grid(gemm256_grid(T, N)), block(g256::WAVES * 64);
     const bf16_t *xa = (const bf16_t *)x, *wa = (const bf16_t *)w, *ra = (const bf16_t *)res;
     bf16_t *ya = (bf16_t *)y;
-    if (epi == 0)
-        hipLaunchKernelGGL((g256::k_gemm_pp<0>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
-    else if (epi == 1)
-        hipLaunchKernelGGL((g256::k_gemm_pp<1>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
-    else
-        hipLaunchKernelGGL((g256::k_gemm_pp<2>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K);
+    switch (epi) {
+    case 0: hipLaunchKernelGGL((g256::k_gemm_pp<0>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    case 1: hipLaunchKernelGGL((g256::k_gemm_pp<1>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    case 2: hipLaunchKernelGGL((g256::k_gemm_pp<2>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    case 3: hipLaunchKernelGGL((g256::k_gemm_pp<3>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    case 4: hipLaunchKernelGGL((g256::k_gemm_pp<4>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    case 5: hipLaunchKernelGGL((g256::k_gemm_pp<5>), grid, block, g256::kLds, st, xa, wa, bias, ra, ya, T, N, K, aux0, rstats, partials); break;
+    default: return fail(CRH_E_INTERNAL, "gemm256: epilogue %d", epi);
+    }
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
@@ -1052,6 +1267,9 @@ int gemm_lds_attr()
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<3, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
     }
     return CRH_OK;
 }
@@ -1176,6 +1394,67 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
         hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
     else
         hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+// ---- LayerNorm folded into the GEMMs around it (ABI 4; kernels and arithmetic: the comment above struct LnAcc)
+int crh_gemm_bf16_lnin(const void *x, const float *row_stats, const void *w_scaled, const float *colsum, const float *bias_folded, void *y,
+                       int T, int N, int K, int act, void *stream)
+{
+    if (!x || !row_stats || !w_scaled || !colsum || !bias_folded || !y) return fail(CRH_E_INVALID, "gemm_lnin: NULL pointer");
+    if (T <= 0 || N <= 0 || K <= 0 || N % BN || K % BK) return fail(CRH_E_INVALID, "gemm_lnin: shape T=%d N=%d K=%d (need N%%128==0, K%%64==0)", T, N, K);
+    if (act != 0 && act != 1) return fail(CRH_E_INVALID, "gemm_lnin: act=%d (0 none, 1 gelu)", act);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const GemmKernel which = choose_gemm(T, N, K, act);
+    if (which == GEMM_MID)
+        return act == 1 ? launch_mid<4>(x, w_scaled, bias_folded, nullptr, y, T, N, K, st, colsum, row_stats)
+                        : launch_mid<3>(x, w_scaled, bias_folded, nullptr, y, T, N, K, st, colsum, row_stats);
+    if (which == GEMM_PP) return launch_gemm256(3 + act, x, w_scaled, bias_folded, nullptr, y, T, N, K, st, colsum, row_stats, nullptr);
+    const dim3 grid(gemm_grid(T, N));
+    CRH_TRY(gemm_lds_attr());
+    if (act == 1)
+        hipLaunchKernelGGL((k_gemm_nt<4, 0>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w_scaled, bias_folded,
+                           (const bf16_t *)nullptr, (bf16_t *)y, T, N, K, colsum, row_stats);
+    else
+        hipLaunchKernelGGL((k_gemm_nt<3, 0>), grid, dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w_scaled, bias_folded,
+                           (const bf16_t *)nullptr, (bf16_t *)y, T, N, K, colsum, row_stats);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_gemm_bf16_res_lnstats(const void *x, const void *w, const float *bias, const void *residual, const float *res_stats,
+                              const float *res_gamma, float eps, void *y, float *partials, float *stats_out, int T, int N, int K, void *stream)
+{
+    if (!x || !w || !bias || !residual || !y || !partials || !stats_out) return fail(CRH_E_INVALID, "gemm_res_lnstats: NULL pointer");
+    if (res_stats && !res_gamma) return fail(CRH_E_INVALID, "gemm_res_lnstats: residual statistics without the gain");
+    if (N != 768) return fail(CRH_E_INVALID, "gemm_res_lnstats: N=%d (built for 768)", N);
+    if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res_lnstats: shape T=%d K=%d", T, K);
+    if (y == residual) return fail(CRH_E_INVALID, "gemm_res_lnstats: the output must not overwrite the residual");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const GemmKernel which = choose_gemm(T, N, K, 0);
+    if (which == GEMM_MID) {
+        CRH_TRY(launch_mid<5>(x, w, bias, residual, y, T, N, K, st, res_gamma, res_stats, partials));
+    } else if (which == GEMM_PP) {
+        CRH_TRY(launch_gemm256(5, x, w, bias, residual, y, T, N, K, st, res_gamma, res_stats, partials));
+    } else {
+        CRH_TRY(gemm_lds_attr());
+        hipLaunchKernelGGL((k_gemm_nt<5, 0>), dim3(gemm_grid(T, N)), dim3(GEMM_WAVES * 64), kGemmLds, st, (const bf16_t *)x, (const bf16_t *)w, bias,
+                           (const bf16_t *)residual, (bf16_t *)y, T, N, K, res_gamma, res_stats, partials);
+        CRH_HIP(hipGetLastError());
+    }
+    static_assert(kLnSlots == 768 / 32, "k_ln_finalize is built for 768 columns");
+    hipLaunchKernelGGL(k_ln_finalize, dim3((unsigned)ceil_div(T, 64)), dim3(64), 0, st, (const float *)partials, stats_out, T, eps);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_layernorm_apply(const void *x, const float *row_stats, const float *gamma, const float *beta, void *y, int T, int N, void *stream)
+{
+    if (!x || !row_stats || !gamma || !beta || !y) return fail(CRH_E_INVALID, "layernorm_apply: NULL pointer");
+    if (N != 768 || T <= 0) return fail(CRH_E_INVALID, "layernorm_apply: shape T=%d N=%d (built for 768)", T, N);
+    hipLaunchKernelGGL(k_ln_apply768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t *)x, row_stats, gamma, beta,
+                       (bf16_t *)y, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

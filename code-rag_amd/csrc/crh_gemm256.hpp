@@ -41,20 +41,32 @@ constexpr int R_AH0 = 0, R_WH0 = 1, R_WH1 = 2, R_AH1 = 3;
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
-// EPI: 0 bias, 1 bias + erf-GELU, 2 bias + residual.  M arbitrary (guarded), N % 256 == 0, K % 128 == 0, K >= 256.
+// EPI: 0 bias, 1 bias + erf-GELU, 2 bias + residual; the LayerNorm-folded forms (round 5):
+//   3 / 4  "LN in": A holds UN-normalised rows r, W the weights scaled by the LayerNorm gain (W' = gamma (.) W), and the epilogue
+//          finishes the normalisation per row m: y = rstd_m (acc - mu_m c_n) + b'_n = fma(acc, rstd_m, fma(nmr_m, c_n, b'_n)) with
+//          rstats[m] = (rstd_m, nmr_m = -mu_m rstd_m), aux0 = c_n = sum_k W'_nk, bias = b'_n = b_n + sum_k beta_k W_nk; 4 adds erf-GELU.
+//   5      "residual + stats out": out = bf16(acc + bias_n + h), h the residual -- normalised on the fly when rstats is given:
+//          out = bf16(fma(fma(r, rstd_m, nmr_m), aux0_n /*gamma*/, acc + bias_n)) with bias = this GEMM's bias + the LayerNorm's beta
+//          (folded on the host), else out = bf16((acc + bias_n) + r), which is epilogue 2.  `out` is the UN-normalised input of
+//          the next LayerNorm; per (row, 32-column slot) the mean and the sum of squared deviations of the rounded outputs go to
+//          partials[m][n / 32] (crh_encoder.hip: LnAcc / ln_join_row; k_ln_finalize turns a row's N / 32 pairs into (rstd, nmr)).
+// M arbitrary (guarded), N % 256 == 0, K % 128 == 0, K >= 256.
 // DBG (timing ablations, wrong results): 1 = no global stores in the epilogue, 2 = no epilogue at all, 4 = 1.5x the LDS-DMA
 // (one more half-tile every other phase, into the idle epilogue images) and 4 more fragment reads per phase -- the load a
 // two-pass schedule with half-height wave tiles would put on the main loop
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict__ A, const bf16_t *__restrict__ W,
                                                         const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                        bf16_t *__restrict__ C, int M, int N, int K)
+                                                        bf16_t *__restrict__ C, int M, int N, int K,
+                                                        const float *__restrict__ aux0 = nullptr,
+                                                        const float *__restrict__ rstats = nullptr, float *__restrict__ partials = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, c16 = lane & 15;
+    const int lane_ = lane, g_ = g, c16_ = c16;   // (epilogue 5 shadows the three with opaque copies)
 
     // ---- tile list of this workgroup: same XCD-aware order as k_gemm_nt (contiguous panel range per XCD label,
     // super-tiles of 4 panels x 8 column tiles)
@@ -234,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
     // after the advance, to this one in phases 2-3
     int m0 = 0, n0 = 0;   // origin of the tile being computed
     float4 bv[4];         // its bias fragment, fetched under the tile's last 16 MFMAs (FW1 is dead by then)
+    float b_lin = 0.f, g_lin = 1.f;   // EPI 5: bias and LayerNorm gain of column n0 + wc*64 + lane
     auto extra_load = [&](const bool dma) __attribute__((always_inline)) {
         if (!(DBG & 4)) return;
         if (dma && c_more) {
@@ -279,8 +292,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
         stage(R_WH0, B);
         extra_load(false);
         if (last && !(DBG & 2)) {
+            if (EPI == 5) {   // one column per lane (2 registers; the epilogue hands a fragment round by ds_bpermute when it needs it)
+                b_lin = bias[n0 + wc * 64 + lane];
+                g_lin = rstats != nullptr ? aux0[n0 + wc * 64 + lane] : 1.0f;
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wc * 64 + nt * 16 + 4 * g);
+                for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4 *>(bias + n0 + wc * 64 + nt * 16 + 4 * g);
+            }
         }
         mem_end();
         mfma16(0, 1, FW0, first);
@@ -310,6 +328,102 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
                 for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
             continue;
         }
+        if constexpr (EPI == 5) {
+            // ---- epilogue 5 (header comment): out = bf16(acc + bias + h), h = the residual, normalised on the fly when rstats is given;
+            // statistics of the rounded outputs per (row, 32-column slot).  Registers are what bounds this epilogue (the 128
+            // accumulators stay live while it runs): bias and gain live lane-linear in one register each and a 4-column fragment
+            // is fetched by ds_bpermute per (q, nt); the residual rows and their statistics come two m-tiles at a time, one step ahead.
+            const bool res_ln = rstats != nullptr;
+            // (lane-derived values made opaque HERE: otherwise every address this block derives from them is hoisted out of the
+            // tile loop as an invariant, lives across the main loop and is spilled there -- the k_gemm_pp header's warning)
+            int c16 = c16_, g = g_, lane = lane_;
+            asm volatile("" : "+v"(c16), "+v"(g), "+v"(lane));
+            // residual rows in two batches of 4 m-tiles (two q steps each), as epilogue 2 fetches them: the second batch is
+            // issued once the first 32 rows have left, into the registers their accumulators vacated -- two exposed round trips
+            // per tile instead of four (a batch per q step measured 9 us per tile over epilogue 2)
+            u32x2 rq[2][4][4];   // [batch][nt][mt & 3]
+            float2 sq[2][4];     // [batch][mt & 3]
+            auto load_b = [&](int batch) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    int m = m0 + grp * 128 + (batch * 4 + mi) * 16 + c16;
+                    m = m < M ? m : M - 1;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        rq[batch][nt][mi] = *reinterpret_cast<const u32x2 *>(R + (size_t)m * N + n0 + wc * 64 + nt * 16 + 4 * g);
+                    sq[batch][mi] = res_ln ? *reinterpret_cast<const float2 *>(rstats + 2 * (size_t)m) : float2{1.f, 0.f};
+                }
+            };
+            load_b(0);
+            // bias and gain of the wave's 64 columns as a 512-byte table in LDS: the last k-tile (always buffer 1) has read its
+            // WH1 region for the last time in phase 1, and the next tile's first k-tile refills it in phase 0 -- this wave's own two
+            // pieces land on this wave's slice, after its epilogue in program order.  A fragment is then two ds_read_b128 per
+            // (q, nt) (the first version fetched it with 8 ds_bpermute and waited for each group: 128 per tile, 3.7 us of waits)
+            const uint32_t tbl = (uint32_t)(kBuf + R_WH1 * kHalf) + (uint32_t)wave * 2048u;      // byte offset into smem (stays an LDS address)
+            *reinterpret_cast<float *>(smem + tbl + lane * 4) = b_lin;
+            *reinterpret_cast<float *>(smem + tbl + 256 + lane * 4) = g_lin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == 1) load_b(1);
+                uint32_t tq = tbl + (uint32_t)g * 16u;
+                asm volatile("" : "+v"(tq));     // (per q: the fragments are not hoisted out of the loop into 32 registers)
+                LnAcc la[2][2];   // [mh][slot of the wave's two]
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(smem + tq + nt * 64), g4 = *reinterpret_cast<const float4 *>(smem + tq + 256 + nt * 64);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        const int mt = q * 2 + mh;
+                        const u32x2 r2 = rq[mt >> 2][nt][mt & 3];
+                        const float2 s2 = sq[mt >> 2][mt & 3];
+                        const float h0 = bf2f(r2.x & 0xffffu), h1 = bf2f(r2.x >> 16), h2 = bf2f(r2.y & 0xffffu), h3 = bf2f(r2.y >> 16);
+                        // (without statistics: rstd = 1, nmr = 0, gain = 1 -- fma(h, 1, 0) = h and fma(h, 1, v) = v + h: epilogue 2's bits)
+                        const float v0 = __builtin_fmaf(__builtin_fmaf(h0, s2.x, s2.y), gg[0], acc[nt][mt][0] + bb[0]);
+                        const float v1 = __builtin_fmaf(__builtin_fmaf(h1, s2.x, s2.y), gg[1], acc[nt][mt][1] + bb[1]);
+                        const float v2 = __builtin_fmaf(__builtin_fmaf(h2, s2.x, s2.y), gg[2], acc[nt][mt][2] + bb[2]);
+                        const float v3 = __builtin_fmaf(__builtin_fmaf(h3, s2.x, s2.y), gg[3], acc[nt][mt][3] + bb[3]);
+                        u32x2 o;
+                        o.x = pack2(v0, v1);
+                        o.y = pack2(v2, v3);
+                        ln_acc4(la[mh][nt >> 1], (nt & 1) == 0, bf2f(o.x & 0xffffu), bf2f(o.x >> 16), bf2f(o.y & 0xffffu), bf2f(o.y >> 16));
+                        const int row = mh * 16 + c16;
+                        const int chunk = nt * 2 + (g >> 1);
+                        *reinterpret_cast<u32x2 *>(cimg + row * 128 + ((chunk ^ (row & 7)) << 4) + (g & 1) * 8) = o;
+                    }
+                }
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    const float2 p0 = ln_join_row(ln_acc_done8(la[mh][0])), p1 = ln_join_row(ln_acc_done8(la[mh][1]));
+                    const int m = m0 + grp * 128 + (q * 2 + mh) * 16 + c16;
+                    if (g == 0 && m < M)
+                        *reinterpret_cast<float4 *>(partials + ((size_t)m * (N >> 5) + ((n0 >> 5) + wc * 2)) * 2) = float4{p0.x, p0.y, p1.x, p1.y};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3), chunk = lane & 7;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(cimg + row * 128 + ((chunk ^ (row & 7)) << 4));
+                    const int m = m0 + grp * 128 + q * 32 + row;
+                    if (m < M) *reinterpret_cast<u32x4 *>(C + (size_t)m * N + n0 + wc * 64 + chunk * 8) = v;
+                }
+            }
+            after_epi = (m0 + BM <= M) ? 3 : 0;
+            continue;
+        }
+        // epilogues 3 / 4 ("LN in"): per-row (rstd, -mu rstd) of the A rows and the column sums of the gain-scaled weights
+        constexpr bool kLnIn = EPI == 3 || EPI == 4;
+        float2 st[8];
+        float4 cv[4];
+        if (kLnIn) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                int m = m0 + grp * 128 + mt * 16 + c16;
+                m = m < M ? m : M - 1;
+                st[mt] = *reinterpret_cast<const float2 *>(rstats + 2 * (size_t)m);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4 *>(aux0 + n0 + wc * 64 + nt * 16 + 4 * g);
+        }
         // residual rows in two batches of 4 m-tiles (the second is issued once the first 32 rows have left, into the
         // registers their accumulators vacated: all 8 at once would not fit beside the 128 accumulators)
         u32x2 rv[2][4][4];   // [batch][nt][mt & 3]
@@ -333,7 +447,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
                     const int mt = q * 2 + mh;
                     float v0 = acc[nt][mt][0] + bv[nt].x, v1 = acc[nt][mt][1] + bv[nt].y, v2 = acc[nt][mt][2] + bv[nt].z,
                           v3 = acc[nt][mt][3] + bv[nt].w;
-                    if (EPI == 1) {
+                    if (kLnIn) {
+                        v0 = __builtin_fmaf(acc[nt][mt][0], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].x, bv[nt].x));
+                        v1 = __builtin_fmaf(acc[nt][mt][1], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].y, bv[nt].y));
+                        v2 = __builtin_fmaf(acc[nt][mt][2], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].z, bv[nt].z));
+                        v3 = __builtin_fmaf(acc[nt][mt][3], st[mt].x, __builtin_fmaf(st[mt].y, cv[nt].w, bv[nt].w));
+                    }
+                    if (EPI == 1 || EPI == 4) {
                         const f32x2_t ga = gelu_erf2(f32x2_t{v0, v1}), gb = gelu_erf2(f32x2_t{v2, v3});
                         v0 = ga.x;
                         v1 = ga.y;

@@ -44,6 +44,13 @@ class EncoderConfig:
     type_vocab_size: int = 10
     layer_norm_eps: float = 1e-5
     pad_token_id: int = 1
+    # LayerNorm folded into the GEMMs around it (csrc/crh_encoder.hip, "LayerNorm folded ..."): the residual stream stays
+    # un-normalised between kernels, no [T, 768] pass just to normalise.  Built, bit-stable across batch sizes, and MEASURED
+    # 1.9 % SLOWER than the two LayerNorm kernels per layer at 65 k tokens (profiles/r05_ln_fold_ab.md: the producer GEMMs'
+    # epilogue work -- the residual's LayerNorm and the row statistics -- runs with the matrix pipe idle and costs what the two
+    # memory-bound passes cost), so it is OPT-IN: its results sit slightly closer to the fp32 forward (one rounding of a
+    # normalised activation less per LayerNorm: tests/test_encoder_oracle.py), which is what one may want it for.
+    ln_fold: bool = os.environ.get("CODERAG_HIP_LN_FOLD", "0") == "1"
 
     @classmethod
     def from_hf_json(cls, path: str) -> "EncoderConfig":
@@ -169,17 +176,44 @@ class HipUniXcoder:
         self.type0 = dev("embeddings.token_type_embeddings.weight", bf)[0].contiguous()
         self.emb_g, self.emb_b = dev("embeddings.LayerNorm.weight", f32), dev("embeddings.LayerNorm.bias", f32)
         self.layers = []
+
+        def host(name):      # f32 master on the host (the folding below is done once, in f64, from the unrounded weights)
+            t = weights[name]
+            t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t
+            return t.detach().to(device="cpu", dtype=torch.float64)
+
+        def fold(w64, b64, gain64, beta64):
+            """LayerNorm(x) @ w^T + b = rstd (x @ (w * gain)^T - mu * colsum) + (b + w @ beta): the gain-scaled weights (bf16),
+            the column sums OF THE ROUNDED VALUES (what the matrix pipe actually adds up) and the folded bias."""
+            ws = (w64 * gain64[None, :]).to(torch.float32).to(bf)
+            colsum = ws.to(torch.float64).sum(1).to(torch.float32)
+            bias = (b64 + w64 @ beta64).to(torch.float32)
+            return ws.to(self.device).contiguous(), colsum.to(self.device).contiguous(), bias.to(self.device).contiguous()
         for i in range(cfg.num_layers):
             p = f"encoder.layer.{i}."
             qkv_w = torch.cat([dev(p + f"attention.self.{n}.weight", bf) for n in ("query", "key", "value")], 0).contiguous()
             qkv_b = torch.cat([dev(p + f"attention.self.{n}.bias", f32) for n in ("query", "key", "value")], 0).contiguous()
-            self.layers.append(dict(
+            ly = dict(
                 qkv_w=qkv_w, qkv_b=qkv_b,
                 o_w=dev(p + "attention.output.dense.weight", bf), o_b=dev(p + "attention.output.dense.bias", f32),
                 ln1_g=dev(p + "attention.output.LayerNorm.weight", f32), ln1_b=dev(p + "attention.output.LayerNorm.bias", f32),
                 f1_w=dev(p + "intermediate.dense.weight", bf), f1_b=dev(p + "intermediate.dense.bias", f32),
                 f2_w=dev(p + "output.dense.weight", bf), f2_b=dev(p + "output.dense.bias", f32),
-                ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32)))
+                ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32))
+            if cfg.ln_fold:
+                g1, b1 = host(p + "attention.output.LayerNorm.weight"), host(p + "attention.output.LayerNorm.bias")
+                ly["f1_ws"], ly["f1_c"], ly["f1_bf"] = fold(host(p + "intermediate.dense.weight"), host(p + "intermediate.dense.bias"), g1, b1)
+                ly["f2_bf"] = (host(p + "output.dense.bias") + b1).to(torch.float32).to(self.device).contiguous()      # FFN2's bias + LayerNorm-1's beta
+                del ly["f1_w"]                   # (the unscaled FFN1 weights are not used by the folded forward)
+                if i > 0:                        # layer 0 reads the embedding LayerNorm's output, which is materialised
+                    q = f"encoder.layer.{i - 1}."
+                    g2, b2 = host(q + "output.LayerNorm.weight"), host(q + "output.LayerNorm.bias")
+                    wq = torch.cat([host(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
+                    bq = torch.cat([host(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
+                    ly["qkv_ws"], ly["qkv_c"], ly["qkv_bf"] = fold(wq, bq, g2, b2)
+                    ly["o_bf"] = (host(p + "attention.output.dense.bias") + b2).to(torch.float32).to(self.device).contiguous()
+                    del ly["qkv_w"]
+            self.layers.append(ly)
         # raw addresses, taken once: a forward is 62 launches with ~10 pointer arguments each, and on the one-query path the
         # host's enqueue time is as long as the GPU's chain of kernels
         # models are shared process-wide (load_unixcoder) while the pinned staging slots below are per model: one submission at a time
@@ -208,6 +242,10 @@ class HipUniXcoder:
         eps, check = cfg.layer_norm_eps, ffi.check
         gemm, gemm_ln, attn = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln, L_.crh_attn_fwd_varlen
         check(L_.crh_embed_ln(int(ids.data_ptr()), *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, L, H, st))
+        if cfg.ln_fold:
+            self._layers_folded(px, px1, pqkv, pctx, phid, T, st, lambda: check(attn(pqkv, pkm, pctx, B, L, cfg.num_heads, st)))
+            check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
+            return sent
         for ly in self._layer_ptrs:
             check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
             check(attn(pqkv, pkm, pctx, B, L, cfg.num_heads, st))
@@ -216,6 +254,38 @@ class HipUniXcoder:
             check(gemm_ln(phid, ly["f2_w"], ly["f2_b"], px1, ly["ln2_g"], ly["ln2_b"], eps, px, T, H, F, st))
         check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
         return sent
+
+    def _layers_folded(self, px, px1, pqkv, pctx, phid, T, st, attention) -> None:
+        """The twelve layers with the LayerNorms folded into the GEMMs around them (csrc/crh_encoder.hip, "LayerNorm folded into
+        the GEMMs around it"; reference arithmetic: modeling_roberta.py:329-340, 387-398).  ``px`` holds the embedding LayerNorm's
+        output on entry and the LAST LayerNorm's output on exit; in between the residual stream is un-normalised rows + per-row
+        (rstd, -mu rstd): per layer 4 GEMMs (two of them followed by the tiny statistics kernel) + attention."""
+        torch, L_ = self._torch, ffi.lib()
+        cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
+        st1 = torch.empty((T, 2), dtype=torch.float32, device=self.device)
+        st2 = torch.empty((T, 2), dtype=torch.float32, device=self.device)
+        part = torch.empty((T, H // 32, 2), dtype=torch.float32, device=self.device)
+        pst1, pst2, ppart = int(st1.data_ptr()), int(st2.data_ptr()), int(part.data_ptr())
+        eps, check = cfg.layer_norm_eps, ffi.check
+        gemm, lnin, res = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_lnin, L_.crh_gemm_bf16_res_lnstats
+        prev = None
+        for ly in self._layer_ptrs:
+            _yield_gil()
+            if prev is None:
+                check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
+            else:
+                check(lnin(px, pst2, ly["qkv_ws"], ly["qkv_c"], ly["qkv_bf"], pqkv, T, 3 * H, H, 0, st))
+            attention()
+            if prev is None:        # residual = the embedding LayerNorm's output, as it is
+                check(res(pctx, ly["o_w"], ly["o_b"], px, None, None, eps, px1, ppart, pst1, T, H, H, st))
+            else:                   # residual = LayerNorm-2 of the previous layer, worked out from its un-normalised rows
+                check(res(pctx, ly["o_w"], ly["o_bf"], px, pst2, prev["ln2_g"], eps, px1, ppart, pst1, T, H, H, st))
+            check(lnin(px1, pst1, ly["f1_ws"], ly["f1_c"], ly["f1_bf"], phid, T, F, H, 1, st))
+            check(res(phid, ly["f2_w"], ly["f2_bf"], px1, pst1, ly["ln1_g"], eps, px, ppart, pst2, T, H, F, st))
+            prev = ly
+        check(L_.crh_layernorm_apply(px, pst2, prev["ln2_g"], prev["ln2_b"], px, T, H, st))
+        # (st1 / st2 / part go back to torch's caching allocator here while the launches above may still be queued: the allocator
+        # hands a block out again only to work ordered behind them on this stream, like every other buffer of a forward)
 
     def forward_packed(self, ids, row_off, Lmax: int, verify: bool = False):
         """The forward on a batch WITHOUT padding: ``ids`` int32 CUDA tensor [T] (the rows' tokens back to back), ``row_off``
@@ -241,7 +311,10 @@ class HipUniXcoder:
         eps, check = cfg.layer_norm_eps, ffi.check
         gemm, gemm_ln = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln
         check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, T, Lmax, H, st))
-        for ly in self._layer_ptrs:
+        if cfg.ln_fold:
+            self._layers_folded(px, px1, pqkv, pctx, phid, T, st,
+                                lambda: check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, T, Lmax, cfg.num_heads, st)))
+        for ly in (() if cfg.ln_fold else self._layer_ptrs):
             # (a launch loop re-takes the interpreter lock microseconds after every ctypes call: a thread that waits for it -- the
             # store's worker answering a query beside this indexing run -- would otherwise get it only at the 5 ms switch
             # interval, per hop; yielding once per layer costs a microsecond and lets it in within a layer's ~1 ms)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRH_ABI_VERSION 3
+#define CRH_ABI_VERSION 4
 
 /* status codes */
 #define CRH_OK 0
@@ -297,6 +297,29 @@ int crh_gemm_bf16_bias(const void *x, const void *w, const float *bias, void *y,
 int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, const void *residual,
                               const float *gamma, const float *beta, float eps, void *y, int T, int N,
                               int K, void *stream);
+
+/* The same post-LN block with the LayerNorm FOLDED into the GEMMs around it (ABI 4; modeling_roberta.py:329-340,387-398 --
+ * RobertaSelfOutput / RobertaOutput: dense, dropout, LayerNorm(hidden + input): the arithmetic these two entry points split
+ * differently).  The residual stream stays UN-normalised between kernels; no [T, 768] tensor is read or written just to be
+ * normalised (crh_encoder.hip, "LayerNorm folded into the GEMMs around it").
+ *
+ * crh_gemm_bf16_res_lnstats -- the producer (O-projection, FFN2): y[T, 768] = bf16(x @ w^T + bias + h), h = the previous
+ *   LayerNorm's output worked out from ITS un-normalised rows: h = (residual * rstd + nmr) * res_gamma (+ its beta, which the
+ *   caller folds into `bias`), with res_stats[T][2] = (rstd, nmr = -mu * rstd); res_stats == NULL: h = residual as it is.
+ *   Also writes stats_out[T][2] = (rstd, nmr) of the rows of y as stored (what the next LayerNorm needs); `partials` is
+ *   caller-provided scratch of T * (N / 32) * 2 floats.  y must not alias residual.  N == 768.
+ * crh_gemm_bf16_lnin -- the consumer (QKV, FFN1): y[T, N] = act(LayerNorm(x) @ w^T + bias) computed as
+ *   rstd * (x @ w_scaled^T - mu * colsum) + bias_folded, with x the un-normalised rows, row_stats[T][2] = (rstd, nmr) from the
+ *   call above, w_scaled[N, K] = w * gamma (per k, rounded to bf16), colsum[N] = sum_k w_scaled[n][k] (of the ROUNDED values),
+ *   bias_folded[N] = bias + w @ beta. */
+int crh_gemm_bf16_res_lnstats(const void *x, const void *w, const float *bias, const void *residual, const float *res_stats,
+                              const float *res_gamma, float eps, void *y, float *partials, float *stats_out, int T, int N, int K,
+                              void *stream);
+int crh_gemm_bf16_lnin(const void *x, const float *row_stats, const void *w_scaled, const float *colsum, const float *bias_folded,
+                       void *y, int T, int N, int K, int act, void *stream);
+/* y[T, 768] = bf16((x * rstd + nmr) * gamma + beta): the LayerNorm output itself from statistics already known (the last layer of a
+ * folded forward: the masked mean pool, unixcoder_provider.py:152-154, reads normalised rows).  y may be x. */
+int crh_layernorm_apply(const void *x, const float *row_stats, const float *gamma, const float *beta, void *y, int T, int N, void *stream);
 
 /* Bidirectional self-attention with key masking.  qkv [B*L, 3*H*64] bf16 exactly as the QKV GEMM writes it
  * (q | k | v thirds, head-major inside each), out [B*L, H*64] bf16.  kmask: uint64 [B, ceil(L/64)], bit j of word t

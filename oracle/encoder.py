@@ -99,7 +99,7 @@ def _ln(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.
 
 
 def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray, return_tokens: bool = False,
-            dtype: torch.dtype = torch.float32, bf16_storage: bool = False, device: str = "cpu"):
+            dtype: torch.dtype = torch.float32, bf16_storage: bool = False, device: str = "cpu", ln_fold: bool = False):
     """ids: int [B, L], right- or arbitrarily padded with cfg.pad_token_id.  Returns sentence embeddings [B, H]
     (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155.
 
@@ -108,6 +108,12 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
     fed to the P.V product): the model of "the same computation at the kernels' storage precision" that the GPU
     parity test compares against.  Biases and LayerNorm parameters stay f32 there, as in the kernels.
 
+    ``ln_fold=True`` evaluates the post-LN layers the way the HIP path does since round 5 (csrc/crh_encoder.hip, "LayerNorm folded
+    into the GEMMs around it"): the residual stream stays un-normalised, a consumer GEMM multiplies it by gain-scaled weights and
+    finishes the normalisation per element (``rstd * acc + nmr * colsum + folded bias``), a producer GEMM adds the previous
+    LayerNorm's output worked out on the fly.  Without ``bf16_storage`` this is the same function as the plain path up to f32
+    rounding (tests/test_encoder_oracle.py pins that on CPU); with it, the rounding points are the folded kernels'.
+
     ``device``: where torch evaluates these same fp32 expressions.  "cpu" is the oracle proper (and the timed CPU baseline);
     "cuda" runs the identical plain-torch fp32 graph on the GPU (rocBLAS fp32 GEMMs, no bf16, none of this repo's kernels) so
     that end-to-end parity legs can afford thousands of chunks -- tests/test_c2_gpu.py pins it against the CPU evaluation
@@ -115,6 +121,7 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
     def rb(t):
         return t.to(torch.bfloat16).to(dtype) if bf16_storage else t
     W = to_device(weights, device, dtype)
+    W0 = W                                    # unrounded masters: the folded forms scale these, then round
     if bf16_storage:
         W = {k: (rb(v) if (v.ndim == 2) else v) for k, v in W.items()}
     ids_t = torch.from_numpy(np.asarray(ids, dtype=np.int64)).to(device)
@@ -128,7 +135,48 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
         x = rb(_ln(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], cfg.layer_norm_eps))
         neg = torch.finfo(dtype).min
         key_bias = torch.where(mask, 0.0, neg).to(dtype)[:, None, None, :]          # additive, on keys only
-        for i in range(cfg.num_layers):
+        def attention(q, k, v):
+            s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + key_bias
+            if bf16_storage:   # the kernel normalises AFTER the P.V product: P = exp(s - max) is what gets rounded
+                e = torch.exp(s - s.max(-1, keepdim=True).values)
+                ctx = (rb(e) @ v) / e.sum(-1, keepdim=True)
+            else:
+                ctx = torch.softmax(s, dim=-1) @ v
+            return rb(ctx.transpose(1, 2).reshape(B, L, H))
+
+        def row_stats(r):      # (rstd, nmr = -mu rstd) of rows as stored
+            mu = r.mean(-1, keepdim=True)
+            rstd = 1.0 / torch.sqrt(((r - mu) ** 2).mean(-1, keepdim=True) + cfg.layer_norm_eps)
+            return rstd, -mu * rstd
+
+        def lin_lnin(r, st, wname, bname, gain, beta):
+            """LayerNorm(r) @ w^T + b as rstd (r @ (w gain)^T) + nmr colsum + (b + w @ beta): gain-scaled weights rounded like weights."""
+            ws = rb(W0[wname] * gain[None, :])
+            return st[0] * (r @ ws.T) + st[1] * ws.sum(1) + (W0[bname] + W0[wname] @ beta)
+        r2 = st2 = None
+        for i in (range(cfg.num_layers) if ln_fold else ()):
+            p = f"encoder.layer.{i}."
+            if i == 0:
+                qkv = [rb(x @ W[p + f"attention.self.{n}.weight"].T + W[p + f"attention.self.{n}.bias"]) for n in ("query", "key", "value")]
+            else:
+                pp = f"encoder.layer.{i - 1}."
+                g2, b2 = W[pp + "output.LayerNorm.weight"], W[pp + "output.LayerNorm.bias"]
+                qkv = [rb(lin_lnin(r2, st2, p + f"attention.self.{n}.weight", p + f"attention.self.{n}.bias", g2, b2)) for n in ("query", "key", "value")]
+            ctx = attention(*(t.view(B, L, nh, dh).transpose(1, 2) for t in qkv))
+            o = ctx @ W[p + "attention.output.dense.weight"].T
+            if i == 0:
+                r1 = rb(o + W[p + "attention.output.dense.bias"] + x)
+            else:
+                r1 = rb((r2 * st2[0] + st2[1]) * g2 + (o + (W[p + "attention.output.dense.bias"] + b2)))
+            st1 = row_stats(r1)
+            g1, b1 = W[p + "attention.output.LayerNorm.weight"], W[p + "attention.output.LayerNorm.bias"]
+            h = lin_lnin(r1, st1, p + "intermediate.dense.weight", p + "intermediate.dense.bias", g1, b1)
+            h = rb(h * 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))))
+            r2 = rb((r1 * st1[0] + st1[1]) * g1 + (h @ W[p + "output.dense.weight"].T + (W[p + "output.dense.bias"] + b1)))
+            st2 = row_stats(r2)
+            if i == cfg.num_layers - 1:
+                x = rb((r2 * st2[0] + st2[1]) * W[p + "output.LayerNorm.weight"] + W[p + "output.LayerNorm.bias"])
+        for i in (() if ln_fold else range(cfg.num_layers)):
             p = f"encoder.layer.{i}."
 
             def lin(t, name):
@@ -136,13 +184,7 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
             q = rb(lin(x, "attention.self.query")).view(B, L, nh, dh).transpose(1, 2)
             k = rb(lin(x, "attention.self.key")).view(B, L, nh, dh).transpose(1, 2)
             v = rb(lin(x, "attention.self.value")).view(B, L, nh, dh).transpose(1, 2)
-            s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + key_bias
-            if bf16_storage:   # the kernel normalises AFTER the P.V product: P = exp(s - max) is what gets rounded
-                e = torch.exp(s - s.max(-1, keepdim=True).values)
-                ctx = (rb(e) @ v) / e.sum(-1, keepdim=True)
-            else:
-                ctx = torch.softmax(s, dim=-1) @ v
-            ctx = rb(ctx.transpose(1, 2).reshape(B, L, H))
+            ctx = attention(q, k, v)
             x = rb(_ln(rb(lin(ctx, "attention.output.dense") + x), W[p + "attention.output.LayerNorm.weight"],
                        W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps))
             h = lin(x, "intermediate.dense")

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = ffi.lib()
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
-    assert lib.crh_abi_version() == ffi.ABI_VERSION == 3
+    assert lib.crh_abi_version() == ffi.ABI_VERSION == 4
 
 
 def test_product_library_exports_no_debug_entry_point():

@@ -152,6 +152,108 @@ def test_gemm_residual_layernorm(gpu, T, K):
     _close(torch, y, ref, rel=2 ** -6, abs_=2e-2)           # the pre-LN sum is held in bf16 before normalisation
 
 
+# ---- LayerNorm folded into the GEMMs around it (round 5; csrc/crh_encoder.hip "LayerNorm folded ...", modeling_roberta.py:329-340,387-398)
+# T picks the kernel: a few rows -> k_gemm_mid, thousands -> k_gemm_nt, tens of thousands -> the 256x256 ping-pong kernel; ragged T the guards
+@pytest.mark.parametrize("with_stats", [True, False])
+@pytest.mark.parametrize("T,K", [(1, 768), (40, 3072), (257, 768), (1000, 3072), (4095, 768), (6000, 768), (22100, 3072), (23040, 768), (66000, 768)])
+def test_folded_producer_gemm_residual_and_statistics(gpu, T, K, with_stats):
+    """crh_gemm_bf16_res_lnstats: y = bf16(x @ w^T + bias + h), h = (residual * rstd + nmr) * gamma (or the residual as it is), and
+    the (rstd, nmr) of the rows of y AS STORED."""
+    torch, ffi, dev = _env()
+    g = torch.Generator(device="cpu").manual_seed(K + T)
+    a = torch.randn((T, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((768, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((768,), generator=g).to(dev)
+    res = (3.0 * torch.randn((T, 768), generator=g) + 0.7).to(dev, torch.bfloat16)       # un-normalised rows: some scale, some mean
+    gam = (1 + 0.1 * torch.randn((768,), generator=g)).to(dev)
+    mu = res.float().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(res.float().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    rst = torch.cat([rstd, -mu * rstd], 1).contiguous()
+    y = torch.full((T + 4, 768), 7.0, dtype=torch.bfloat16, device=dev)
+    part = torch.empty((T, 24, 2), dtype=torch.float32, device=dev)
+    st = torch.full((T + 4, 2), 7.0, dtype=torch.float32, device=dev)
+    ffi.check(ffi.lib().crh_gemm_bf16_res_lnstats(a.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), rst.data_ptr() if with_stats else None,
+                                                  gam.data_ptr() if with_stats else None, 1e-5, y.data_ptr(), part.data_ptr(), st.data_ptr(), T, 768, K, 0))
+    h = (res.float() * rst[:, :1] + rst[:, 1:]) * gam if with_stats else res.float()
+    ref = a.float() @ w.float().T + b + h
+    torch.cuda.synchronize()
+    _close(torch, y[:T], ref, rel=2 ** -7, abs_=4e-3)
+    assert bool((y[T:] == 7.0).all()) and bool((st[T:] == 7.0).all())                   # nothing past T
+    yy = y[:T].float()                                                                   # the statistics describe what was stored
+    mu_y = yy.mean(-1, keepdim=True)
+    rstd_y = 1.0 / torch.sqrt(yy.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    assert torch.allclose(st[:T, :1], rstd_y, rtol=2e-5, atol=0) and torch.allclose(st[:T, 1:], -mu_y * rstd_y, rtol=2e-5, atol=2e-6)
+    if not with_stats:      # without statistics this is epilogue 2 (bias + residual, one rounding): the same bits as the old entry point's pre-LN sum
+        y2 = torch.empty((T, 768), dtype=torch.bfloat16, device=dev)
+        one, zero = torch.ones((768,), device=dev), torch.zeros((768,), device=dev)
+        if K > 1024:        # (that entry point adds the residual in the GEMM epilogue only for K > 1024; its LayerNorm then runs in place)
+            ffi.check(ffi.lib().crh_gemm_bf16_bias_res_ln(a.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), one.data_ptr(), zero.data_ptr(), 1e-5,
+                                                          y2.data_ptr(), T, 768, K, 0))
+            torch.cuda.synchronize()
+            _close(torch, y2, torch.nn.functional.layer_norm(yy, (768,), one, zero, 1e-5), rel=2 ** -7, abs_=4e-3)
+
+
+@pytest.mark.parametrize("T,N,act", [(1, 2304, 0), (33, 3072, 1), (500, 2304, 0), (2048, 3072, 1), (5000, 2304, 0), (9300, 3072, 1), (22000, 2304, 0), (66000, 3072, 1)])
+def test_folded_consumer_gemm_finishes_the_layernorm(gpu, T, N, act):
+    """crh_gemm_bf16_lnin on un-normalised rows == the plain GEMM on their LayerNorm, up to bf16 rounding of the gain-scaled weights."""
+    torch, ffi, dev = _env()
+    K = 768
+    g = torch.Generator(device="cpu").manual_seed(N + T)
+    r = (2.5 * torch.randn((T, K), generator=g) - 0.4).to(dev, torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev)
+    b = torch.randn((N,), generator=g).to(dev)
+    gam = (1 + 0.1 * torch.randn((K,), generator=g)).to(dev)
+    bet = (0.1 * torch.randn((K,), generator=g)).to(dev)
+    ws = (w * gam[None, :]).to(torch.bfloat16)
+    colsum = ws.double().sum(1).float().contiguous()
+    bias_f = (b.double() + w.double() @ bet.double()).float().contiguous()
+    mu = r.float().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(r.float().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    rst = torch.cat([rstd, -mu * rstd], 1).contiguous()
+    y = torch.full((T + 4, N), 7.0, dtype=torch.bfloat16, device=dev)
+    ffi.check(ffi.lib().crh_gemm_bf16_lnin(r.data_ptr(), rst.data_ptr(), ws.data_ptr(), colsum.data_ptr(), bias_f.data_ptr(), y.data_ptr(), T, N, K, act, 0))
+    ref = torch.nn.functional.layer_norm(r.float(), (K,), gam, bet, 1e-5) @ w.T + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    torch.cuda.synchronize()
+    _close(torch, y[:T], ref, rel=2 ** -6, abs_=1.5e-2)       # + the gain-scaled weights' own bf16 rounding over K = 768 products
+    assert bool((y[T:] == 7.0).all())
+
+
+def test_a_rows_folded_results_do_not_depend_on_the_batch_it_sits_in(gpu):
+    """The three tiled kernels build a row's statistics from the same per-lane sums joined the same way: a row's output, its statistics
+    and what the consumer makes of them are bit-identical whether the row is computed among 40 rows (k_gemm_mid), 3 000 (k_gemm_nt)
+    or 30 000 (the ping-pong kernel)."""
+    torch, ffi, dev = _env()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    Tbig, K = 30000, 768
+    a = torch.randn((Tbig, K), generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn((768, K), generator=g) / K ** 0.5).to(dev, torch.bfloat16)
+    b = torch.randn((768,), generator=g).to(dev)
+    res = (2.0 * torch.randn((Tbig, 768), generator=g) + 0.3).to(dev, torch.bfloat16)
+    gam = (1 + 0.1 * torch.randn((768,), generator=g)).to(dev)
+    mu = res.float().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(res.float().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    rst = torch.cat([rstd, -mu * rstd], 1).contiguous()
+    w2 = (torch.randn((2304, 768), generator=g) / 768 ** 0.5).to(dev, torch.bfloat16)
+    c2, b2 = w2.double().sum(1).float().contiguous(), torch.randn((2304,), generator=g).to(dev)
+    outs = []
+    for T in (40, 3000, Tbig):
+        y = torch.empty((T, 768), dtype=torch.bfloat16, device=dev)
+        part = torch.empty((T, 24, 2), dtype=torch.float32, device=dev)
+        st = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        ffi.check(ffi.lib().crh_gemm_bf16_res_lnstats(a.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), rst.data_ptr(), gam.data_ptr(), 1e-5,
+                                                      y.data_ptr(), part.data_ptr(), st.data_ptr(), T, 768, K, 0))
+        z = torch.empty((T, 2304), dtype=torch.bfloat16, device=dev)
+        ffi.check(ffi.lib().crh_gemm_bf16_lnin(y.data_ptr(), st.data_ptr(), w2.data_ptr(), c2.data_ptr(), b2.data_ptr(), z.data_ptr(), T, 2304, 768, 0, 0))
+        torch.cuda.synchronize()
+        outs.append((y[:40].clone(), st[:40].clone(), z[:40].clone()))
+    for y, st, z in outs[1:]:
+        assert torch.equal(y.view(torch.int16), outs[0][0].view(torch.int16))
+        assert torch.equal(st.view(torch.int32), outs[0][1].view(torch.int32))
+        assert torch.equal(z.view(torch.int16), outs[0][2].view(torch.int16))
+
+
 def _kmask(torch, valid):                                   # valid: bool [B, L] -> int64 [B, ceil(L/64)] bit words
     B, L = valid.shape
     Lp = (L + 63) // 64 * 64
@@ -224,8 +326,9 @@ ENCODER_TOL = {"tiny": ((0.9999, 1e-2), (0.9995, 3e-2)),
                "hfinit": ((0.99995, 1e-2), (0.9999, 1.5e-2))}
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("name", ["tiny", "base", "hfinit"])
-def test_full_encoder_against_hf_fixture(gpu, name):
+def test_full_encoder_against_hf_fixture(gpu, name, fold):
     """Whole forward against (a) the oracle in its ``bf16_storage`` mode -- f32 arithmetic, bf16 rounding exactly where the
     kernels store bf16 -- and (b) the fp32 HF fixture; tolerances per fixture in ENCODER_TOL.
     ``base`` carries deliberately SHARP weights (O(1) activations, 2/sqrt(H) Q/K scale: attention far from uniform, every
@@ -241,7 +344,7 @@ def test_full_encoder_against_hf_fixture(gpu, name):
     c = [int(v) for v in z["cfg"]]
     kw = dict(vocab_size=c[0], hidden_size=c[1], num_layers=c[2], num_heads=c[3], intermediate_size=c[4],
               max_position_embeddings=c[5], type_vocab_size=c[6], pad_token_id=c[7], layer_norm_eps=float(z["eps"]))
-    cfg = drv.EncoderConfig(**kw)
+    cfg = drv.EncoderConfig(**kw, ln_fold=fold)
     weights = drv.synthetic_weights(cfg, int(z["seed"]), init=init)
     model = drv.HipUniXcoder(weights, cfg, drv.HashTokenizer(cfg.vocab_size), 0)
     ids = torch.from_numpy(z["ids"].astype(np.int32)).to(dev)
@@ -250,7 +353,7 @@ def test_full_encoder_against_hf_fixture(gpu, name):
     def dist(ref):
         cos = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
         return cos.min(), (np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
-    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True))
+    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold))
     cos_b, rel_b = dist(z["sent"])
     print(f"encoder[{name}] vs bf16-storage oracle: cos {cos_a:.6f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.6f} rel {rel_b:.4f}")
     if os.environ.get("CODERAG_TEST_REPORT"):      # (a report file only on request: CODERAG_TEST_REPORT=<path>)
@@ -266,8 +369,9 @@ def test_full_encoder_against_hf_fixture(gpu, name):
     assert np.array_equal(again, got[keep])
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("name", ["tiny", "base", "hfinit"])
-def test_packed_forward_against_hf_fixture(gpu, name):
+def test_packed_forward_against_hf_fixture(gpu, name, fold):
     """The PACKED forward -- what embed_ids / embed_texts / the provider / bench.py run -- fed the fixtures' rows directly
     (tokens back to back, row offsets) against the bf16-storage oracle and the fp32 HF vectors, at ENCODER_TOL: pinned by
     the fixtures themselves, not through the padded forward.  Rows with an interior pad token are part of it."""
@@ -279,7 +383,7 @@ def test_packed_forward_against_hf_fixture(gpu, name):
     c = [int(v) for v in z["cfg"]]
     kw = dict(vocab_size=c[0], hidden_size=c[1], num_layers=c[2], num_heads=c[3], intermediate_size=c[4],
               max_position_embeddings=c[5], type_vocab_size=c[6], pad_token_id=c[7], layer_norm_eps=float(z["eps"]))
-    cfg = drv.EncoderConfig(**kw)
+    cfg = drv.EncoderConfig(**kw, ln_fold=fold)
     weights = drv.synthetic_weights(cfg, int(z["seed"]), init=init)
     model = drv.HipUniXcoder(weights, cfg, drv.HashTokenizer(cfg.vocab_size), 0)
     rows = []
@@ -292,7 +396,7 @@ def test_packed_forward_against_hf_fixture(gpu, name):
     def dist(ref):
         cos = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
         return cos.min(), (np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
-    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True))
+    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold))
     cos_b, rel_b = dist(z["sent"])
     print(f"packed encoder[{name}] vs bf16-storage oracle: cos {cos_a:.6f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.6f} rel {rel_b:.4f}")
     (ca, ra), (cb, rb_) = ENCODER_TOL[name]

@@ -70,3 +70,24 @@ def test_length_bucketing_plan():
     for rows, L in batches:
         assert L % 16 == 0 and L >= max(lengths[i] for i in rows) and L * len(rows) <= 1024
     assert m.plan_batches([], 1024) == []
+
+
+@pytest.mark.parametrize("init", ["sharp", "hf"])
+def test_the_folded_layernorm_form_is_the_same_function(init):
+    """Round 5: the HIP path folds each LayerNorm into the GEMMs around it (rstd (r @ (w gain)^T - mu colsum) + (b + w @ beta) for the
+    consumer; the previous LayerNorm's output worked out on the fly for the producer's residual).  ``ln_fold=True`` restates the
+    forward that way: in f32 it must be the plain forward up to rounding (modeling_roberta.py:329-340, 387-398 are unchanged
+    arithmetic), and at the kernels' storage precision it must sit as close to the fp32 forward as the plain bf16 model does."""
+    import numpy as np
+    from oracle import encoder as orc
+    cfg = orc.EncoderConfig(vocab_size=600, hidden_size=768, num_layers=3, num_heads=12, intermediate_size=3072, max_position_embeddings=130)
+    w = orc.random_weights(cfg, 5, init=init)
+    ids = orc.synthetic_ids(cfg, [20, 64, 37, 9], 3, pad_to=64)
+    plain = orc.forward(w, cfg, ids)
+    folded = orc.forward(w, cfg, ids, ln_fold=True)
+    assert np.abs(plain - folded).max() <= 1e-5 * np.abs(plain).max()
+
+    def rel(x):
+        return (np.linalg.norm(x - plain, axis=1) / np.linalg.norm(plain, axis=1)).max()
+    a, b = rel(orc.forward(w, cfg, ids, bf16_storage=True)), rel(orc.forward(w, cfg, ids, bf16_storage=True, ln_fold=True))
+    assert b <= 1.25 * a, (a, b)

@@ -635,7 +635,7 @@ def test_back_to_back_batches_each_keep_their_own_queries(gpu, bf16, policy):
     torch.cuda.synchronize()
     outs = [_dev_search(idx, torch, qd, k, st) for _, qd, k in batches]
     idx.search_finish(st)
-    assert idx.nomination() == ffi.NOMINATE_INT8 and idx.stats()["fallback_used"] == 0
+    assert idx.nomination() == (ffi.NOMINATE_BF16 if policy == "product default" else ffi.NOMINATE_INT8) and idx.stats()["fallback_used"] == 0
     for (q, _, k), (s, r) in zip(batches, outs):
         es, er = orc.cosine_search(x, q, k, bf16=bf16)
         assert _same(s, r, es, er)
