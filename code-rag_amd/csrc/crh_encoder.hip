@@ -272,6 +272,50 @@ __global__ __launch_bounds__(256) void k_layernorm768_res(bf16_t *__restrict__ x
     }
 }
 
+// LayerNorm(x + residual) with the residual stream kept in F32 (the opt-in fidelity lever of round 5: the GEMMs still read bf16
+// rows, but what a layer adds its output to -- and what twelve layers therefore accumulate their roundings in -- is not rounded to
+// bf16 between layers).  x: the GEMM output (bf16, bias included), replaced by bf16(LayerNorm) for the next GEMM; res32: the f32
+// residual, replaced by the f32 LayerNorm output, the next residual.  One wave per row; 12 bytes per element instead of 6.
+__global__ __launch_bounds__(256) void k_layernorm768_res32(bf16_t *__restrict__ x, float *__restrict__ res32, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bf16_t *p = x + (size_t)r * 768;
+    float *pr = res32 + (size_t)r * 768;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p + i * 256 + lane * 4);
+        const float4 z = *reinterpret_cast<const float4 *>(pr + i * 256 + lane * 4);
+        v[4 * i] = bf2f(w.x & 0xffffu) + z.x;
+        v[4 * i + 1] = bf2f(w.x >> 16) + z.y;
+        v[4 * i + 2] = bf2f(w.y & 0xffffu) + z.z;
+        v[4 * i + 3] = bf2f(w.y >> 16) + z.w;
+        s += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
+    }
+    const float mu = wave_sum(s) * (1.f / 768.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / 768.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + e);
+        const float4 y = float4{(v[4 * i] - mu) * rstd * g.x + b.x, (v[4 * i + 1] - mu) * rstd * g.y + b.y, (v[4 * i + 2] - mu) * rstd * g.z + b.z,
+                                (v[4 * i + 3] - mu) * rstd * g.w + b.w};
+        u32x2 o;
+        o.x = pack2(y.x, y.y);
+        o.y = pack2(y.z, y.w);
+        *reinterpret_cast<u32x2 *>(p + e) = o;
+        *reinterpret_cast<float4 *>(pr + e) = y;
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm folded into the GEMMs around it (round 5)
 //
 // The post-LN layer keeps its residual stream UN-normalised between kernels.  A producer GEMM (O-projection, FFN2; epilogue 5 of
@@ -1394,6 +1438,19 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
         hipLaunchKernelGGL(k_layernorm768_res, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, (const bf16_t *)residual, gamma, beta, eps, T);
     else
         hipLaunchKernelGGL(k_layernorm768, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, gamma, beta, eps, T);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+int crh_gemm_bf16_bias_res32_ln(const void *x, const void *w, const float *bias, float *residual_f32, const float *gamma, const float *beta,
+                                float eps, void *y, int T, int N, int K, void *stream)
+{
+    if (!x || !w || !bias || !residual_f32 || !gamma || !beta || !y) return fail(CRH_E_INVALID, "gemm_res32_ln: NULL pointer");
+    if (N != 768) return fail(CRH_E_INVALID, "gemm_res32_ln: N=%d (the LayerNorm is built for 768)", N);
+    if (T <= 0 || K <= 0 || K % BK) return fail(CRH_E_INVALID, "gemm_res32_ln: shape T=%d K=%d", T, K);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CRH_TRY(launch_tiled(0, x, w, bias, nullptr, y, T, N, K, st));      // bias-only epilogue at every K: the residual joins in f32, below
+    hipLaunchKernelGGL(k_layernorm768_res32, dim3((unsigned)ceil_div(T, 4)), dim3(256), 0, st, (bf16_t *)y, residual_f32, gamma, beta, eps, T);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -51,6 +51,10 @@ class EncoderConfig:
     # memory-bound passes cost), so it is OPT-IN: its results sit slightly closer to the fp32 forward (one rounding of a
     # normalised activation less per LayerNorm: tests/test_encoder_oracle.py), which is what one may want it for.
     ln_fold: bool = os.environ.get("CODERAG_HIP_LN_FOLD", "0") == "1"
+    # The residual stream in f32 (opt-in fidelity lever, round 5): what each layer adds its output to is not rounded to bf16
+    # between layers; the GEMMs are unchanged (bf16 rows in, bf16 out), only the two LayerNorm kernels read and write an f32 copy
+    # beside the bf16 one (12 bytes per element instead of 6: measured cost and gain in bench.py's c2 record / DESIGN.md section 4c).
+    residual_f32: bool = os.environ.get("CODERAG_HIP_RESIDUAL_F32", "0") == "1"
 
     @classmethod
     def from_hf_json(cls, path: str) -> "EncoderConfig":
@@ -64,12 +68,15 @@ class EncoderConfig:
 def synthetic_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dict[str, np.ndarray]:
     """Seeded stand-in weights under HF ``RobertaModel`` state-dict names (no checkpoint exists offline).  The numpy
     Generator stream is machine-independent, so every box regenerates the same tensors.  ``init="hf"``: the statistics of
-    HF's ``_init_weights`` (N(0, 0.02^2) matrices and tables, zero biases, unit LayerNorm) instead of the sharp O(1) ones."""
+    HF's ``_init_weights`` (N(0, 0.02^2) matrices and tables, zero biases, unit LayerNorm) instead of the sharp O(1) ones;
+    ``init="hf_ln"``: between the two -- HF-init matrices with the sharp fixture's biases and LayerNorm gains / biases (a trained
+    checkpoint's LayerNorm parameters are not 1 / 0: bench.py's fidelity leg reports all three)."""
     rng = np.random.default_rng(seed)
     H, F = cfg.hidden_size, cfg.intermediate_size
 
-    hf = init == "hf"
-    if init not in ("sharp", "hf"):
+    hf = init in ("hf", "hf_ln")          # matrices and tables N(0, 0.02^2)
+    hf_vec = init == "hf"                 # ... and zero biases / unit LayerNorm; "hf_ln" keeps the sharp fixture's biases and LayerNorm gains
+    if init not in ("sharp", "hf", "hf_ln"):
         raise ValueError(f"unknown init {init!r}")
 
     def mat(n, k, std):
@@ -77,7 +84,7 @@ def synthetic_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dic
         return rng.standard_normal((n, k), dtype=np.float32) * np.float32(std)
 
     def vec(n, std, mean=0.0):
-        if hf:   # (the draw is still made, so both flavours consume the generator identically)
+        if hf_vec:   # (the draw is still made, so all flavours consume the generator identically)
             return rng.standard_normal(n, dtype=np.float32) * np.float32(0.0) + np.float32(mean)
         return rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean)
     w = {
@@ -200,6 +207,8 @@ class HipUniXcoder:
                 f1_w=dev(p + "intermediate.dense.weight", bf), f1_b=dev(p + "intermediate.dense.bias", f32),
                 f2_w=dev(p + "output.dense.weight", bf), f2_b=dev(p + "output.dense.bias", f32),
                 ln2_g=dev(p + "output.LayerNorm.weight", f32), ln2_b=dev(p + "output.LayerNorm.bias", f32))
+            if cfg.ln_fold and cfg.residual_f32:
+                raise ValueError("ln_fold and residual_f32 are two forms of the LayerNorm step: choose one")
             if cfg.ln_fold:
                 g1, b1 = host(p + "attention.output.LayerNorm.weight"), host(p + "attention.output.LayerNorm.bias")
                 ly["f1_ws"], ly["f1_c"], ly["f1_bf"] = fold(host(p + "intermediate.dense.weight"), host(p + "intermediate.dense.bias"), g1, b1)
@@ -242,8 +251,9 @@ class HipUniXcoder:
         eps, check = cfg.layer_norm_eps, ffi.check
         gemm, gemm_ln, attn = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln, L_.crh_attn_fwd_varlen
         check(L_.crh_embed_ln(int(ids.data_ptr()), *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, L, H, st))
-        if cfg.ln_fold:
-            self._layers_folded(px, px1, pqkv, pctx, phid, T, st, lambda: check(attn(pqkv, pkm, pctx, B, L, cfg.num_heads, st)))
+        if cfg.ln_fold or cfg.residual_f32:
+            layers = self._layers_folded if cfg.ln_fold else self._layers_res32
+            layers(px, px1, pqkv, pctx, phid, T, st, lambda: check(attn(pqkv, pkm, pctx, B, L, cfg.num_heads, st)), x0=x)
             check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
             return sent
         for ly in self._layer_ptrs:
@@ -255,7 +265,26 @@ class HipUniXcoder:
         check(L_.crh_masked_mean_pool(px, pkm, psent, B, L, H, st))
         return sent
 
-    def _layers_folded(self, px, px1, pqkv, pctx, phid, T, st, attention) -> None:
+    def _layers_res32(self, px, px1, pqkv, pctx, phid, T, st, attention, x0=None) -> None:
+        """The twelve layers with the residual stream in f32 (EncoderConfig.residual_f32): the same GEMMs and attention on bf16
+        rows; each LayerNorm adds the GEMM's bf16 output to the F32 residual, writes bf16 for the next GEMM and f32 for the next
+        residual (csrc/crh_encoder.hip, k_layernorm768_res32).  ``px`` holds the embedding LayerNorm's output on entry (bf16: the
+        stream starts from it) and the last LayerNorm's bf16 output on exit."""
+        torch, L_ = self._torch, ffi.lib()
+        cfg, H, F = self.cfg, self.cfg.hidden_size, self.cfg.intermediate_size
+        r32 = x0.to(torch.float32)          # the stream starts from the embedding LayerNorm's bf16 output
+        pr32 = int(r32.data_ptr())
+        eps, check = cfg.layer_norm_eps, ffi.check
+        gemm, gemm_ln32 = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res32_ln
+        for ly in self._layer_ptrs:
+            _yield_gil()
+            check(gemm(px, ly["qkv_w"], ly["qkv_b"], pqkv, T, 3 * H, H, 0, st))
+            attention()
+            check(gemm_ln32(pctx, ly["o_w"], ly["o_b"], pr32, ly["ln1_g"], ly["ln1_b"], eps, px1, T, H, H, st))
+            check(gemm(px1, ly["f1_w"], ly["f1_b"], phid, T, F, H, 1, st))
+            check(gemm_ln32(phid, ly["f2_w"], ly["f2_b"], pr32, ly["ln2_g"], ly["ln2_b"], eps, px, T, H, F, st))
+
+    def _layers_folded(self, px, px1, pqkv, pctx, phid, T, st, attention, x0=None) -> None:
         """The twelve layers with the LayerNorms folded into the GEMMs around them (csrc/crh_encoder.hip, "LayerNorm folded into
         the GEMMs around it"; reference arithmetic: modeling_roberta.py:329-340, 387-398).  ``px`` holds the embedding LayerNorm's
         output on entry and the LAST LayerNorm's output on exit; in between the residual stream is un-normalised rows + per-row
@@ -311,10 +340,10 @@ class HipUniXcoder:
         eps, check = cfg.layer_norm_eps, ffi.check
         gemm, gemm_ln = L_.crh_gemm_bf16_bias, L_.crh_gemm_bf16_bias_res_ln
         check(L_.crh_embed_ln_packed(int(ids.data_ptr()), poff, *self._emb_ptrs, eps, cfg.pad_token_id, px, pkm, B, T, Lmax, H, st))
-        if cfg.ln_fold:
-            self._layers_folded(px, px1, pqkv, pctx, phid, T, st,
-                                lambda: check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, T, Lmax, cfg.num_heads, st)))
-        for ly in (() if cfg.ln_fold else self._layer_ptrs):
+        if cfg.ln_fold or cfg.residual_f32:
+            layers = self._layers_folded if cfg.ln_fold else self._layers_res32
+            layers(px, px1, pqkv, pctx, phid, T, st, lambda: check(L_.crh_attn_fwd_packed(pqkv, poff, pkm, pctx, B, T, Lmax, cfg.num_heads, st)), x0=x)
+        for ly in (() if (cfg.ln_fold or cfg.residual_f32) else self._layer_ptrs):
             # (a launch loop re-takes the interpreter lock microseconds after every ctypes call: a thread that waits for it -- the
             # store's worker answering a query beside this indexing run -- would otherwise get it only at the 5 ms switch
             # interval, per hop; yielding once per layer costs a microsecond and lets it in within a layer's ~1 ms)

@@ -30,7 +30,7 @@ EXPORTS = (
     "crh_search", "crh_search_finish", "crh_search_get_stats", "crh_index_set_tuning",
     "crh_index_set_nomination", "crh_index_get_nomination",
     "crh_merge_topk", "crh_merge_topk_strided", "crh_index_match_rows", "crh_index_set_profiling", "crh_index_get_profile",
-    "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_gemm_bf16_res_lnstats", "crh_gemm_bf16_lnin", "crh_layernorm_apply", "crh_attn_fwd_varlen", "crh_embed_ln",
+    "crh_gemm_bf16_bias", "crh_gemm_bf16_bias_res_ln", "crh_gemm_bf16_res_lnstats", "crh_gemm_bf16_lnin", "crh_layernorm_apply", "crh_gemm_bf16_bias_res32_ln", "crh_attn_fwd_varlen", "crh_embed_ln",
     "crh_masked_mean_pool", "crh_gather_rows_i32", "crh_gather_rows_bytes", "crh_gather_rerank_columns", "crh_rerank_vector",
     "crh_embed_ln_packed", "crh_attn_fwd_packed", "crh_masked_mean_pool_packed", "crh_encoder_finish",
 )
@@ -150,6 +150,7 @@ def _bind(path: Path, debug: bool) -> C.CDLL:
     L.crh_gemm_bf16_res_lnstats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]
     L.crh_gemm_bf16_lnin.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.crh_layernorm_apply.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.crh_gemm_bf16_bias_res32_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, vp]
     L.crh_attn_fwd_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.crh_embed_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]
     L.crh_masked_mean_pool.argtypes = [vp, vp, vp, i32, i32, i32, vp]

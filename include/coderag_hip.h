@@ -298,6 +298,12 @@ int crh_gemm_bf16_bias_res_ln(const void *x, const void *w, const float *bias, c
                               const float *gamma, const float *beta, float eps, void *y, int T, int N,
                               int K, void *stream);
 
+/* The same with the RESIDUAL STREAM IN F32 (ABI 4; opt-in fidelity lever: the reference's forward is fp32 throughout,
+ * unixcoder_provider.py:137-155): y[T, 768] = bf16(LayerNorm(bf16(x @ w^T + bias) + residual_f32)) for the next GEMM, and
+ * residual_f32[T, 768] is REPLACED by the same LayerNorm output in f32 -- the next residual.  N == 768. */
+int crh_gemm_bf16_bias_res32_ln(const void *x, const void *w, const float *bias, float *residual_f32, const float *gamma, const float *beta,
+                                float eps, void *y, int T, int N, int K, void *stream);
+
 /* The same post-LN block with the LayerNorm FOLDED into the GEMMs around it (ABI 4; modeling_roberta.py:329-340,387-398 --
  * RobertaSelfOutput / RobertaOutput: dense, dropout, LayerNorm(hidden + input): the arithmetic these two entry points split
  * differently).  The residual stream stays UN-normalised between kernels; no [T, 768] tensor is read or written just to be

@@ -47,8 +47,9 @@ def random_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dict[s
     rng = np.random.default_rng(seed)
     H, F = cfg.hidden_size, cfg.intermediate_size
 
-    hf = init == "hf"
-    if init not in ("sharp", "hf"):
+    hf = init in ("hf", "hf_ln")          # matrices and tables N(0, 0.02^2)
+    hf_vec = init == "hf"                 # ... and zero biases / unit LayerNorm; "hf_ln" keeps the sharp fixture's biases and LayerNorm gains
+    if init not in ("sharp", "hf", "hf_ln"):
         raise ValueError(f"unknown init {init!r}")
 
     def mat(n, k, std):
@@ -56,7 +57,7 @@ def random_weights(cfg: EncoderConfig, seed: int, init: str = "sharp") -> dict[s
         return (rng.standard_normal((n, k), dtype=np.float32) * np.float32(std))
 
     def vec(n, std, mean=0.0):
-        if hf:   # (the draw is still made, so both flavours consume the generator identically)
+        if hf_vec:   # (the draw is still made, so all flavours consume the generator identically)
             return rng.standard_normal(n, dtype=np.float32) * np.float32(0.0) + np.float32(mean)
         return (rng.standard_normal(n, dtype=np.float32) * np.float32(std) + np.float32(mean))
     w = {
@@ -99,7 +100,8 @@ def _ln(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.
 
 
 def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray, return_tokens: bool = False,
-            dtype: torch.dtype = torch.float32, bf16_storage: bool = False, device: str = "cpu", ln_fold: bool = False):
+            dtype: torch.dtype = torch.float32, bf16_storage: bool = False, device: str = "cpu", ln_fold: bool = False,
+            residual_f32: bool = False):
     """ids: int [B, L], right- or arbitrarily padded with cfg.pad_token_id.  Returns sentence embeddings [B, H]
     (and the token embeddings [B, L, H]).  unixcoder_provider.py:146-155.
 
@@ -113,6 +115,9 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
     finishes the normalisation per element (``rstd * acc + nmr * colsum + folded bias``), a producer GEMM adds the previous
     LayerNorm's output worked out on the fly.  Without ``bf16_storage`` this is the same function as the plain path up to f32
     rounding (tests/test_encoder_oracle.py pins that on CPU); with it, the rounding points are the folded kernels'.
+
+    ``residual_f32=True`` (with ``bf16_storage``): the HIP path's opt-in form in which the residual stream is NOT rounded between
+    layers -- every LayerNorm adds the (rounded) GEMM output to the unrounded previous LayerNorm output; GEMM inputs are rounded.
 
     ``device``: where torch evaluates these same fp32 expressions.  "cpu" is the oracle proper (and the timed CPU baseline);
     "cuda" runs the identical plain-torch fp32 graph on the GPU (rocBLAS fp32 GEMMs, no bf16, none of this repo's kernels) so
@@ -185,6 +190,16 @@ def forward(weights: dict[str, np.ndarray], cfg: EncoderConfig, ids: np.ndarray,
             k = rb(lin(x, "attention.self.key")).view(B, L, nh, dh).transpose(1, 2)
             v = rb(lin(x, "attention.self.value")).view(B, L, nh, dh).transpose(1, 2)
             ctx = attention(q, k, v)
+            if residual_f32:     # xr: the unrounded stream; x = rb(xr) is what the GEMMs read
+                if i == 0:
+                    xr = x
+                xr = _ln(rb(lin(ctx, "attention.output.dense")) + xr, W[p + "attention.output.LayerNorm.weight"],
+                         W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps)
+                h = lin(rb(xr), "intermediate.dense")
+                h = rb(h * 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))))
+                xr = _ln(rb(lin(h, "output.dense")) + xr, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], cfg.layer_norm_eps)
+                x = rb(xr)
+                continue
             x = rb(_ln(rb(lin(ctx, "attention.output.dense") + x), W[p + "attention.output.LayerNorm.weight"],
                        W[p + "attention.output.LayerNorm.bias"], cfg.layer_norm_eps))
             h = lin(x, "intermediate.dense")

@@ -326,9 +326,9 @@ ENCODER_TOL = {"tiny": ((0.9999, 1e-2), (0.9995, 3e-2)),
                "hfinit": ((0.99995, 1e-2), (0.9999, 1.5e-2))}
 
 
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("form", ["two LayerNorm kernels", "ln_fold", "residual_f32"])
 @pytest.mark.parametrize("name", ["tiny", "base", "hfinit"])
-def test_full_encoder_against_hf_fixture(gpu, name, fold):
+def test_full_encoder_against_hf_fixture(gpu, name, form):
     """Whole forward against (a) the oracle in its ``bf16_storage`` mode -- f32 arithmetic, bf16 rounding exactly where the
     kernels store bf16 -- and (b) the fp32 HF fixture; tolerances per fixture in ENCODER_TOL.
     ``base`` carries deliberately SHARP weights (O(1) activations, 2/sqrt(H) Q/K scale: attention far from uniform, every
@@ -344,7 +344,8 @@ def test_full_encoder_against_hf_fixture(gpu, name, fold):
     c = [int(v) for v in z["cfg"]]
     kw = dict(vocab_size=c[0], hidden_size=c[1], num_layers=c[2], num_heads=c[3], intermediate_size=c[4],
               max_position_embeddings=c[5], type_vocab_size=c[6], pad_token_id=c[7], layer_norm_eps=float(z["eps"]))
-    cfg = drv.EncoderConfig(**kw, ln_fold=fold)
+    fold, res32 = form == "ln_fold", form == "residual_f32"     # the default and the two opt-in forms of the LayerNorm step (EncoderConfig)
+    cfg = drv.EncoderConfig(**kw, ln_fold=fold, residual_f32=res32)
     weights = drv.synthetic_weights(cfg, int(z["seed"]), init=init)
     model = drv.HipUniXcoder(weights, cfg, drv.HashTokenizer(cfg.vocab_size), 0)
     ids = torch.from_numpy(z["ids"].astype(np.int32)).to(dev)
@@ -353,7 +354,7 @@ def test_full_encoder_against_hf_fixture(gpu, name, fold):
     def dist(ref):
         cos = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
         return cos.min(), (np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
-    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold))
+    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold, residual_f32=res32))
     cos_b, rel_b = dist(z["sent"])
     print(f"encoder[{name}] vs bf16-storage oracle: cos {cos_a:.6f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.6f} rel {rel_b:.4f}")
     if os.environ.get("CODERAG_TEST_REPORT"):      # (a report file only on request: CODERAG_TEST_REPORT=<path>)
@@ -369,9 +370,9 @@ def test_full_encoder_against_hf_fixture(gpu, name, fold):
     assert np.array_equal(again, got[keep])
 
 
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("form", ["two LayerNorm kernels", "ln_fold", "residual_f32"])
 @pytest.mark.parametrize("name", ["tiny", "base", "hfinit"])
-def test_packed_forward_against_hf_fixture(gpu, name, fold):
+def test_packed_forward_against_hf_fixture(gpu, name, form):
     """The PACKED forward -- what embed_ids / embed_texts / the provider / bench.py run -- fed the fixtures' rows directly
     (tokens back to back, row offsets) against the bf16-storage oracle and the fp32 HF vectors, at ENCODER_TOL: pinned by
     the fixtures themselves, not through the padded forward.  Rows with an interior pad token are part of it."""
@@ -383,7 +384,8 @@ def test_packed_forward_against_hf_fixture(gpu, name, fold):
     c = [int(v) for v in z["cfg"]]
     kw = dict(vocab_size=c[0], hidden_size=c[1], num_layers=c[2], num_heads=c[3], intermediate_size=c[4],
               max_position_embeddings=c[5], type_vocab_size=c[6], pad_token_id=c[7], layer_norm_eps=float(z["eps"]))
-    cfg = drv.EncoderConfig(**kw, ln_fold=fold)
+    fold, res32 = form == "ln_fold", form == "residual_f32"     # the default and the two opt-in forms of the LayerNorm step (EncoderConfig)
+    cfg = drv.EncoderConfig(**kw, ln_fold=fold, residual_f32=res32)
     weights = drv.synthetic_weights(cfg, int(z["seed"]), init=init)
     model = drv.HipUniXcoder(weights, cfg, drv.HashTokenizer(cfg.vocab_size), 0)
     rows = []
@@ -396,7 +398,7 @@ def test_packed_forward_against_hf_fixture(gpu, name, fold):
     def dist(ref):
         cos = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
         return cos.min(), (np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)).max()
-    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold))
+    cos_a, rel_a = dist(orc.forward(weights, orc.EncoderConfig(**kw), z["ids"], bf16_storage=True, ln_fold=fold, residual_f32=res32))
     cos_b, rel_b = dist(z["sent"])
     print(f"packed encoder[{name}] vs bf16-storage oracle: cos {cos_a:.6f} rel {rel_a:.4f}; vs HF fp32: cos {cos_b:.6f} rel {rel_b:.4f}")
     (ca, ra), (cb, rb_) = ENCODER_TOL[name]

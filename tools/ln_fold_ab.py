@@ -20,8 +20,8 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(1234)
 lengths = np.clip(np.round(np.exp(rng.normal(np.log(160.0), 0.8, 4000))), 8, 512).astype(np.int64)
 models = {}
-for fold in (False, True):
-    cfg = drv.EncoderConfig(ln_fold=fold)
+for fold in (False, True, "residual_f32"):
+    cfg = drv.EncoderConfig(residual_f32=True) if fold == "residual_f32" else drv.EncoderConfig(ln_fold=fold)
     models[fold] = drv.HipUniXcoder(drv.synthetic_weights(cfg, 23), cfg, drv.HashTokenizer(cfg.vocab_size), 0)
 m0 = models[False]
 rows = [np.concatenate([[0, 5, 2], rng.integers(16, m0.cfg.vocab_size, int(L) - 4), [2]]).astype(np.int32) if L >= 4 else np.array([0, 5, 2, 2], np.int32) for L in lengths]
@@ -38,9 +38,9 @@ for fold, m in models.items():
 torch.cuda.synchronize()
 cos = [float(torch.nn.functional.cosine_similarity(a, b).min()) for a, b in zip(out[True], out[False])]
 print(f"{len(batches)} packed batches, {tok} tokens; folded vs unfolded embeddings: min cosine {min(cos):.6f}")
-times = {False: [], True: []}
+times = {k: [] for k in models}
 for r in range(rounds):
-    for fold in (False, True):
+    for fold in models:
         m = models[fold]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -48,7 +48,9 @@ for r in range(rounds):
             m.forward_packed(i, o, L)
         torch.cuda.synchronize()
         times[fold].append((time.perf_counter() - t0) * 1e3 / len(batches))
-for fold in (False, True):
+for fold in models:
     print(f"ln_fold={fold}: ms per batch by round {[round(t, 3) for t in times[fold]]}  median {np.median(times[fold]):.3f}")
 a, b = np.median(times[False]), np.median(times[True])
 print(f"folded / unfolded = {b / a:.4f}  ({(1 - b / a) * 100:+.2f} % time)")
+c = np.median(times["residual_f32"])
+print(f"residual_f32 / default = {c / a:.4f}")
