@@ -155,9 +155,11 @@ def test_a_rank_that_dies_mid_run_takes_the_others_down_instead_of_hanging_them(
         assert procs[0].poll() is None and procs[1].poll() is None, "the rehearsal ended before the kill"
         procs[1].send_signal(signal.SIGKILL)
         t0 = time.time()
-        out, err = procs[0].communicate(timeout=60)
+        # (were rank 1 still importing torch when it was killed -- a cold container -- rank 0 gives up in the rendezvous instead, after the
+        # 30 s collective time-out set above: non-zero all the same, hence the generous limits)
+        out, err = procs[0].communicate(timeout=240)
         assert procs[0].returncode not in (0, None), (procs[0].returncode, err[-500:])
-        assert time.time() - t0 < 45
+        assert time.time() - t0 < 180
         assert out.strip() == ""                                   # no line that could be taken for a measurement
     finally:
         for p in procs:
