@@ -571,15 +571,21 @@ def load_unixcoder(model: str, extra: dict | None = None, device: int | None = N
     from .settings import get_settings
     extra = extra or {}
     device = get_settings().hip_device if device is None else device
-    key = (model, device, extra.get("synthetic_weights"))
+    # the two opt-in forms of the LayerNorm step (EncoderConfig: fidelity levers) can be asked for per provider
+    # (``ProviderConfig.extra={"residual_f32": True}``); unset, the environment's / the dataclass's defaults hold
+    forms = {k: bool(extra[k]) for k in ("ln_fold", "residual_f32") if k in extra}
+    key = (model, device, extra.get("synthetic_weights"), tuple(sorted(forms.items())))
     if key in _MODELS:
         return _MODELS[key]
     if extra.get("synthetic_weights") is not None:
-        cfg = EncoderConfig(num_layers=int(extra.get("num_layers", 12)))
+        cfg = EncoderConfig(num_layers=int(extra.get("num_layers", 12)), **forms)
         m = HipUniXcoder(synthetic_weights(cfg, int(extra["synthetic_weights"])), cfg, HashTokenizer(cfg.vocab_size), device)
     elif os.path.isdir(model):
         import torch
         cfg = EncoderConfig.from_hf_json(os.path.join(model, "config.json"))
+        if forms:
+            import dataclasses
+            cfg = dataclasses.replace(cfg, **forms)
         st_path, bin_path = os.path.join(model, "model.safetensors"), os.path.join(model, "pytorch_model.bin")
         if os.path.exists(st_path):
             from safetensors.torch import load_file

@@ -469,6 +469,24 @@ def test_provider_end_to_end(gpu):
     assert not np.allclose(many[0], many[1], atol=1e-3)
 
 
+@pytest.mark.parametrize("form", ["residual_f32", "ln_fold"])
+def test_provider_extras_select_the_opt_in_forms_of_the_layernorm_step(gpu, form):
+    """``ProviderConfig.extra={"residual_f32": True}`` / ``{"ln_fold": True}``: the fidelity levers per provider,
+    separate singletons from the default model, embeddings within bf16 distance of the default's."""
+    import asyncio
+    _env()
+    from coderag_amd.providers import HipUniXcoderProvider, ProviderConfig
+    base = HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model="synthetic", extra={"synthetic_weights": 3, "num_layers": 2}))
+    lever = HipUniXcoderProvider(ProviderConfig(provider="unixcoder-hip", model="synthetic", extra={"synthetic_weights": 3, "num_layers": 2, form: True}))
+    texts = ["def add(a, b):\n    return a + b", "class Foo:\n    pass", "x = 1"]
+    a = np.asarray(asyncio.run(base.embed_batch(texts)))
+    b = np.asarray(asyncio.run(lever.embed_batch(texts)))
+    assert getattr(lever._load().cfg, form) is True and getattr(base._load().cfg, form) is False
+    assert lever._load() is not base._load()
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() > 0.999 and not np.array_equal(a, b)
+
+
 def test_checkpoint_directory_with_native_tokenizer(gpu, tmp_path):
     """A local checkpoint directory (config.json + model.safetensors + vocab.json + merges.txt, as microsoft/unixcoder-base
     ships them; built here from seeded weights and a locally trained vocabulary) loads through load_unixcoder with the
