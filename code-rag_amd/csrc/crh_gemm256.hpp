@@ -86,11 +86,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
     const int my_tiles = by_panel ? cnt * nb : cnt;
     const int ntl = jx < my_tiles ? (my_tiles - jx + bpx - 1) / bpx : 0;
     if (ntl == 0) return;   // whole workgroup, before any barrier
+    // Epilogues 2 / 5 (the FFN2 of a layer: A = the 400 MB the FFN1 before it has just written, in THIS order, each XCD label walking
+    // its own range of panels) walk the row panels from the last to the first: every label starts on the rows it wrote last, which
+    // are still in its L2 / the last-level cache, instead of on the ones written first and evicted since (+0.3-0.7 % of the encoder
+    // leg on two of three devices, level on the third: profiles/r05_ffn2_panel_order.txt).  Order only: a tile's bits do not change.
+    constexpr bool kLastFirst = EPI == 2 || EPI == 5;
     auto tile_origin = [&](int ts, int &tm0, int &tn0) {
         const int u = jx + ts * bpx;
         if (!by_panel) {
             const int tile = first + u;
-            tm0 = (tile / nb) * BM;
+            tm0 = (kLastFirst ? panels - 1 - tile / nb : tile / nb) * BM;
             tn0 = (tile % nb) * BN;
             return;
         }
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
         const int sc = ug / bsz, ub = ug - sc * bsz;
         const int wn_ = (nb - sc * WN) < WN ? (nb - sc * WN) : WN;
         const int pm = ub / wn_, pn = ub - pm * wn_;
-        tm0 = (first + sr * HM + pm) * BM;
+        tm0 = (kLastFirst ? panels - 1 - (first + sr * HM + pm) : first + sr * HM + pm) * BM;
         tn0 = (sc * WN + pn) * BN;
     };
 
