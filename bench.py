@@ -230,7 +230,7 @@ def contract_line(out: dict) -> dict:
     roof = out.get("roofline")
     if isinstance(roof, dict):
         r = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "launches",
-                                         "algorithmic_bytes_per_launch", "whole_step_frac")}
+                                         "algorithmic_bytes_per_launch", "step_bytes", "whole_step_frac")}
         b = roof.get("bf16_scan")
         if isinstance(b, dict):
             r["bf16_scan"] = {k: _r(b.get(k)) for k in ("kernel", "kernel_ms", "achieved", "frac", "algorithmic_bytes_per_launch", "ms_per_step",
@@ -589,13 +589,27 @@ def scan_kernel_name(D, mode):
     return f"k_scan<{D // 16},1,16,8,{qb}>"
 
 
-def scan_roofline(rows, D, scan_ms, launches, mode):
+def i8_sample_record() -> bool:
+    """Whether the library's int8 scan records the sample tiles' upper ends (its default; CODERAG_HIP_I8_SAMPLE_RECORD=0 turns it off)."""
+    return os.environ.get("CODERAG_HIP_I8_SAMPLE_RECORD", "1")[:1] != "0"
+
+
+def scan_roofline(rows, D, scan_ms, launches, mode, stats=None):
     """Algorithmic bytes of one pass: the int8 copy is 1 byte per element + one f32 scale per row, the bf16 tiles 2 bytes per
-    element; every mode reads its copy of the corpus once (the three-launch form's seed scan is outside the timed kernel)."""
-    alg = float(rows) * (D + 4) if mode == 2 else float(rows) * D * 2
+    element; every mode reads its copy of the corpus once (the three-launch form's seed scan is outside the timed kernel).
+    Since round 5 the int8 PASS does not read the sample tiles again (the sample launch before it recorded their rows' upper ends,
+    32 bytes per lane and query block): its bytes are the other tiles + that record -- `algorithmic_bytes_per_launch` is what the
+    timed kernel reads by design, `step_bytes` is every row once (the whole step: sample launch + pass)."""
+    step_bytes = float(rows) * (D + 4) if mode == 2 else float(rows) * D * 2
+    alg = step_bytes
+    sample_tiles = None
+    if mode == 2 and i8_sample_record() and stats and stats.get("batches"):
+        sample_tiles = stats["seed_tiles"] / stats["batches"]
+        alg = step_bytes - sample_tiles * 32 * (D + 4) + sample_tiles * 64 * (32 if D == 1536 else 64)
     ach = alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
            "kernel": scan_kernel_name(D, mode), "kernel_ms": scan_ms, "launches": launches, "algorithmic_bytes_per_launch": alg,
+           "step_bytes": step_bytes, "sample_tiles_not_read_again": sample_tiles,
            "bytes_per_row": (D + 4) if mode == 2 else D * 2,
            "nomination": ("int8 copy of the rows (i8 MFMA, exact integer dot, per-row error intervals)" if mode == 2 else "bf16 tiles (bf16 MFMA)")
                          + "; every returned id and score: canonical f32 arithmetic on the stored rows"}
@@ -603,7 +617,8 @@ def scan_roofline(rows, D, scan_ms, launches, mode):
         # the scan is three launches since late round 4 (no grid-wide wait); the timed kernel is the third.  The first two --
         # 8192 sample tiles (~200 MB read again by the pass) and the thresholds -- are outside `kernel_ms` and inside
         # `ms_per_step` / `whole_step_frac`, like the query preparation and the selection (profiles/: kernel trace of this command)
-        out["kernel_is"] = "the pass over the copy: the third of the scan's three launches (k_scan_i8<..,1> sample tiles and <..,2> thresholds run before it, not in kernel_ms)"
+        out["kernel_is"] = ("the pass over the copy: the third of the scan's three launches (k_scan_i8<..,1> sample tiles and <..,2> thresholds run before it, not in "
+                            "kernel_ms); it takes the sample tiles' candidates from the record the first launch left and reads the other tiles")
     return out
 
 
@@ -809,12 +824,12 @@ def run(args, json_fd) -> None:
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt * (N / 1e7)
     scan_ms = scan_ms_total / max(1, scan_launches)
-    roof = scan_roofline(N, D, scan_ms, scan_launches, nom_mode)
+    roof = scan_roofline(N, D, scan_ms, scan_launches, nom_mode, stats)
     roof["traffic"] = traffic
-    roof["whole_step_frac"] = roof["algorithmic_bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS   # the whole step on the pass's bytes
+    roof["whole_step_frac"] = roof["step_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS   # the whole step: every row's bytes once
     if scan3_ms:
         roof["scan_three_launches_ms"] = scan3_ms
-        roof["scan_three_launches_frac"] = roof["algorithmic_bytes_per_launch"] / (scan3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["scan_three_launches_frac"] = roof["step_bytes"] / (scan3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     roof["traffic_source"] = ("profiles/pmc_scan.json (separate rocprofv3 --pmc passes of this kernel's sources; FETCH_SIZE x2 per the gfx950 guide)"
                               if traffic else traffic_note)
     out = {
@@ -877,7 +892,7 @@ def run(args, json_fd) -> None:
         res = {"workload": f"{N}x{D} {args.dtype}, batch-{B} top-{K}, filter language == code 1 of 3 (uniform)",
                "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7), "unit": out["unit"], "ms_per_step": r["ms_per_step"],
                "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
-               "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], idx.nomination()), "search_stats": r["stats"]}
+               "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], idx.nomination(), r["stats"]), "search_stats": r["stats"]}
         if orc is not None:
             m = min(200_000, head.shape[0])
             res["parity"] = subsample_parity(np, ffi, orc, head[:m], head_codes[:m], qs, K, dtype, local_rank, filters=[(0, 1)])
@@ -902,7 +917,7 @@ def run(args, json_fd) -> None:
         # roofline" speaks of) sits in the HEADLINE's roofline block beside the int8 pass's figure on the bytes IT reads
         out["roofline"]["bf16_scan"] = {"kernel": roof16["kernel"], "kernel_ms": roof16["kernel_ms"], "achieved": roof16["achieved"], "frac": roof16["frac"],
                                         "algorithmic_bytes_per_launch": roof16["algorithmic_bytes_per_launch"], "ms_per_step": r["ms_per_step"],
-                                        "whole_step_frac": roof16["algorithmic_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "whole_step_frac": roof16["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "identical_to_headline": same,
                                         "what": "the same batch on the same index with the int8 copy switched off (crh_index_set_nomination): "
                                                 "the one-launch scan over the bf16 tiles, 2 bytes per element"}
@@ -924,8 +939,8 @@ def run(args, json_fd) -> None:
                 kqd = torch.from_numpy(kq).to(dev)
                 r = timed_search(torch, kidx, kqd, K, None, args.sub_steps, 3, stream)
                 mode = kidx.nomination()
-                roof_k = scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode)
-                roof_k["whole_step_frac"] = roof_k["algorithmic_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                roof_k = scan_roofline(N, D, r["scan_ms"], r["scan_launches"], mode, r["stats"])
+                roof_k["whole_step_frac"] = roof_k["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                 st = r["stats"]
                 gs = r["scores"].cpu().numpy()
                 res = {"workload": f"{N}x{D} {args.dtype} {kind} corpus, batch-{B} top-{K}", "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7),
@@ -997,7 +1012,7 @@ def run(args, json_fd) -> None:
             res = {"workload": f"{N}x{D} f32 store (bf16 MFMA scan nominates, f32 master re-scores), batch-{B} top-{K}",
                    "value": B / (r["ms_per_step"] * 1e-3) * (N / 1e7), "unit": out["unit"], "ms_per_step": r["ms_per_step"],
                    "steps": args.sub_steps, "step_ms_device": r["step_ms_device"],
-                   "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], f32.nomination()), "search_stats": r["stats"],
+                   "roofline": scan_roofline(N, D, r["scan_ms"], r["scan_launches"], f32.nomination(), r["stats"]), "search_stats": r["stats"],
                    "hbm_resident_bytes": float(N) * D * (7 if f32.nomination() == 2 else 6),
                    "recall_at_k_of_the_bf16_store_vs_this_store_full_corpus": full}
             if orc is not None:
@@ -1200,7 +1215,7 @@ def config5_leg(np, torch, ffi, dist, idx, qd, N, B, K, rank, world, row_base, s
             "value": world * B / wall * (N / 1e7), "unit": "queries/s per 10M-row shard (row.query pairs/s / 1e7), re-ranked",
             "ms_per_step": wall * 1e3, "steps": steps, "ms_per_step_one_batch_at_a_time": wall_one * 1e3, "rerank_ms_per_batch": rerank * 1e3,
             "host_hybrid_ranker_ms_per_batch": t_host * 1e3, "survivors": survivors,
-            "roofline": scan_roofline(N, 768, scan, launches, idx.nomination()),
+            "roofline": scan_roofline(N, 768, scan, launches, idx.nomination(), idx.stats()),
             "store_sharded": sharded,
             "parity": {"identical_to_host_hybrid_ranker": bool(ok), "queries": B,
                        "what": "survivors, order, f64 final scores, the four signals and the source label of every query"}}

@@ -204,6 +204,21 @@ __device__ __forceinline__ void prep_query_i8(const float *src /* the canonical 
 // k_scan_fused still has): the waits, during which 3/4 of the workgroups idle, cost more than the two launch boundaries that replace
 // them (1.325 -> 1.312 ms per batch and 1.383 -> 1.377 on two boxes, interleaved pairs), and a kernel without a grid-wide wait
 // needs nobody resident: no time-out, no recovery path, no resting window for this scan.
+// bf16 bits of x rounded towards +inf (an upper end stays an upper end): positive values round their magnitude up, negative ones are cut
+__device__ __forceinline__ uint32_t bf16_bits_up(float x)
+{
+    const uint32_t u = f32_bits(x);
+    return (u >> 31) ? (u >> 16) : ((u + 0xffffu) >> 16);
+}
+// The pass's p-th tile when the sample tiles (0, S, 2S, ... (G - 1) S) are NOT scanned again: the tiles in between, in index order.
+__device__ __forceinline__ int nonsample_tile(int p, int G, int S)
+{
+    const int per = S - 1, full = G * per;               // (S == 1: no tile is left for the pass and nobody calls this)
+    if (p >= full) return G * S + (p - full);
+    const int blk = p / per;
+    return blk * S + 1 + (p - blk * per);
+}
+
 template <int KS8, int WAVES, int RING, int QB, int PART>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     const u32x4 *__restrict__ x8, const float *__restrict__ srow, const unsigned int *__restrict__ dn_bits,
@@ -211,8 +226,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     uint32_t *__restrict__ gkey, float *__restrict__ tau_g, int k, float c_abs, float sqrt_dim, int nq, u32x4 *__restrict__ wave_lists,
     int wave_cap, unsigned int *__restrict__ qcount, u32x2 *__restrict__ qlist, float *__restrict__ qlo, int qcap,
     SearchStatus *__restrict__ status, const u32x4 *__restrict__ xt, const float *__restrict__ xf32,
-    const float *__restrict__ qn, const u32x4 *__restrict__ xrow)
+    const float *__restrict__ qn, const u32x4 *__restrict__ xrow, u32x4 *__restrict__ shi = nullptr)
 {
+    // `shi` (round 5): the sample launch keeps the UPPER ends of every row of its tiles (bf16, rounded up: QB * 32 bytes per lane and
+    // tile, 4 KB per tile at 64 queries, 33.5 MB for 8192 tiles), and the pass takes the sample tiles' candidates from there instead
+    // of reading those tiles (201 MB) and multiplying them a second time; it then walks the other tiles only.
     static_assert(PART >= 1 && PART <= 3, "sample tiles / thresholds / pass");
     static_assert(KS8 % RING == 0, "the ring must divide the pieces of a tile (slot s % RING holds piece s of every tile)");
     constexpr int NT = WAVES * 64, NQS = QB * 32, NB = NT < 1024 ? NT : 1024;
@@ -391,6 +409,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
             scan_tile(xp, xn, acc);
             float hi[QB][16];
             intervals(acc, sr, hi);
+            if (shi != nullptr) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        u32x4 pk;
+                        pk.x = bf16_bits_up(hi[b][8 * v + 0]) | (bf16_bits_up(hi[b][8 * v + 1]) << 16);
+                        pk.y = bf16_bits_up(hi[b][8 * v + 2]) | (bf16_bits_up(hi[b][8 * v + 3]) << 16);
+                        pk.z = bf16_bits_up(hi[b][8 * v + 4]) | (bf16_bits_up(hi[b][8 * v + 5]) << 16);
+                        pk.w = bf16_bits_up(hi[b][8 * v + 6]) | (bf16_bits_up(hi[b][8 * v + 7]) << 16);
+                        shi[((size_t)g * (QB * 2) + b * 2 + v) * 64 + lane] = pk;
+                    }
+            }
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
                 // (ord(lower end) with its five low bits given to the row's number inside the tile: rounded DOWN, still a lower
@@ -502,7 +533,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
     }
     if constexpr (PART == 2) return;
     // ---- 3. the pass: the first corpus loads, then the query image behind them
-    if (gw < ntiles) prime(tile_ptr(gw));
+    const bool stored = shi != nullptr;                     // the sample tiles' upper ends are on record: the pass walks the other tiles
+    const int npass = stored ? ntiles - G : ntiles;        // positions of the pass
+    auto order = [&](int p) { return stored ? nonsample_tile(p, G, S) : p; };   // position in the pass -> tile
+    if (gw < npass) prime(tile_ptr(order(gw)));
     for (int i = tid; i < QB * 2 * KS8 * 64; i += NT) qs[i] = qfrag8[i];
     CRH_STAMP(5);
     if (tid < NQS) tau_s[tid] = tau_g[tid];
@@ -511,49 +545,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
 #pragma unroll
     for (int b = 0; b < QB; ++b) tq[b] = tau_s[b * 32 + (lane & 31)];
 
-    // every tile: rows whose UPPER end reaches the query's threshold become candidates (hi, row, query, lo)
-    int i = gw;
-    const u32x4 *xp = tile_ptr(i < ntiles ? i : 0);
-    while (i < ntiles) {
-        // Which tile a wave scans next is decided as the pass goes, at both levels.  The pass is cut into chunks of WAVES consecutive
-        // tiles; a workgroup starts on chunk blockIdx.x and draws further chunks from ONE counter in device memory
-        // (status->next_chunk), its waves draw the tiles of a chunk from a counter in LDS.  Inside a workgroup: the SIMD issues its
-        // older wave first, and with a fixed list per wave the younger four finished 80-130 us after the older four on half the
-        // loads in flight.  Across workgroups: the even XCDs stream faster than the odd ones (their workgroups were done ~100 us
-        // before the last); this pass is not purely HBM-bound, so -- unlike the bf16 scan, where the same hand-out only cost its
-        // bookkeeping -- what the early finishers leave does not speed the others up, and sharing the tail does: kernel 1.282 / 1.302 /
-        // 1.285 / 1.283 -> 1.236 / 1.236 / 1.241 / 1.239 ms, interleaved runs on one box (profiles/r03_chunk_feed_ab.txt).  The wave that draws a chunk's first
-        // tile fetches the NEXT chunk's number (one device atomic per WAVES tiles, a tile time ahead of its first use) and publishes
-        // it in LDS with its slot number; a wave reads the entry right after its draw.  Chunks past the end make tiles past the
-        // end: a wave stops at the first one (the counter only grows, so every later draw is past the end as well).
-#if !defined(CRH_I8_STATIC)
-        int inext_l = 0;
-        if (lane == 0) {
-            const int m = atomicAdd(&next_m, 1);
-            const unsigned int j = (unsigned int)(m / WAVES), w = (unsigned int)(m % WAVES);
-            if (w == 0) {
-                const unsigned int c = gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&cslot[(j + 1) % 8], ((unsigned long long)(j + 1) << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            unsigned long long e;
-            while (((e = __hip_atomic_load(&cslot[j % 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) != j) __builtin_amdgcn_s_sleep(1);
-            const unsigned int c = (unsigned int)e;
-            inext_l = c > 0x7fffffffu / WAVES ? 0x7fffffff : (int)(c * WAVES + w);
-        }
-        const int inext = __builtin_amdgcn_readfirstlane(inext_l);
-#else
-        const int inext = i + total;
-#endif
-        const int64_t tile = i;
-        const u32x4 *xn = (inext < ntiles) ? tile_ptr(inext) : xp;
-        const uint32_t vmask = rowmask[tile];
-        float sr[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
-        i32x16 acc[QB][2];
-        scan_tile(xp, xn, acc);
-        float hi[QB][16];
-        intervals(acc, sr, hi);
+    // Rows whose UPPER end reaches the query's threshold become candidates (hi, row, query; the lower end follows in the hand-over).
+    // `rounded`: the upper ends come from the sample launch's record (rounded up to bf16): the hand-over allows for that rounding
+    // when it works out the lower end.
+    auto emit_tile = [&](int64_t tile, uint32_t vmask, const float (&hi)[QB][16], uint32_t rounded) __attribute__((always_inline)) {
         // Which of the lane's 16 x QB values pass: one word per lane (bit 16 b + r), the validity of the lane's rows folded in.
         uint32_t pmask = 0u;
 #pragma unroll
@@ -592,13 +587,77 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
                     e.x = f32_bits(hv);
                     e.y = rowbase + (uint32_t)((r & 3) + 8 * (r >> 2));
                     e.z = (uint32_t)((bit >> 4) * 32 + (lane & 31));
-                    e.w = 0u;
+                    e.w = rounded;
                     mylist[pos] = e;
                     atomicAdd(&qcnt_l[e.z], 1u);
                 }
                 ++pos;
             } while (m != 0u);
         }
+    };
+    // the sample tiles, from the record of their upper ends: sample tile g of this wave's share, 32 bytes per lane and query block
+    if (stored) {
+        for (int g = gw; g < G; g += total) {
+            float hi[QB][16];
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const u32x4 pk = shi[((size_t)g * (QB * 2) + b * 2 + v) * 64 + lane];
+                    const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[b][8 * v + 2 * e] = bits_f32(w4[e] << 16);
+                        hi[b][8 * v + 2 * e + 1] = bits_f32(w4[e] & 0xffff0000u);
+                    }
+                }
+            const int64_t tile = (int64_t)g * S;
+            emit_tile(tile, rowmask[tile], hi, 1u);
+        }
+    }
+    int i = gw;
+    const u32x4 *xp = tile_ptr(i < npass ? order(i) : 0);
+    while (i < npass) {
+        // Which tile a wave scans next is decided as the pass goes, at both levels.  The pass is cut into chunks of WAVES consecutive
+        // tiles; a workgroup starts on chunk blockIdx.x and draws further chunks from ONE counter in device memory
+        // (status->next_chunk), its waves draw the tiles of a chunk from a counter in LDS.  Inside a workgroup: the SIMD issues its
+        // older wave first, and with a fixed list per wave the younger four finished 80-130 us after the older four on half the
+        // loads in flight.  Across workgroups: the even XCDs stream faster than the odd ones (their workgroups were done ~100 us
+        // before the last); this pass is not purely HBM-bound, so -- unlike the bf16 scan, where the same hand-out only cost its
+        // bookkeeping -- what the early finishers leave does not speed the others up, and sharing the tail does: kernel 1.282 / 1.302 /
+        // 1.285 / 1.283 -> 1.236 / 1.236 / 1.241 / 1.239 ms, interleaved runs on one box (profiles/r03_chunk_feed_ab.txt).  The wave that draws a chunk's first
+        // tile fetches the NEXT chunk's number (one device atomic per WAVES tiles, a tile time ahead of its first use) and publishes
+        // it in LDS with its slot number; a wave reads the entry right after its draw.  Chunks past the end make tiles past the
+        // end: a wave stops at the first one (the counter only grows, so every later draw is past the end as well).
+#if !defined(CRH_I8_STATIC)
+        int inext_l = 0;
+        if (lane == 0) {
+            const int m = atomicAdd(&next_m, 1);
+            const unsigned int j = (unsigned int)(m / WAVES), w = (unsigned int)(m % WAVES);
+            if (w == 0) {
+                const unsigned int c = gridDim.x + __hip_atomic_fetch_add(&status->next_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&cslot[(j + 1) % 8], ((unsigned long long)(j + 1) << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned long long e;
+            while (((e = __hip_atomic_load(&cslot[j % 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) != j) __builtin_amdgcn_s_sleep(1);
+            const unsigned int c = (unsigned int)e;
+            inext_l = c > 0x7fffffffu / WAVES ? 0x7fffffff : (int)(c * WAVES + w);
+        }
+        const int inext = __builtin_amdgcn_readfirstlane(inext_l);
+#else
+        const int inext = i + total;
+#endif
+        const int64_t tile = order(i);
+        const u32x4 *xn = (inext < npass) ? tile_ptr(order(inext)) : xp;
+        const uint32_t vmask = rowmask[tile];
+        float sr[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sr[j] = srow[(size_t)tile * 32 + j];
+        i32x16 acc[QB][2];
+        scan_tile(xp, xn, acc);
+        float hi[QB][16];
+        intervals(acc, sr, hi);
+        emit_tile(tile, vmask, hi, 0u);
         xp = xn;
         i = inext;
     }
@@ -667,7 +726,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_i8(
                     o.y = cnd[j].y;
                     qlist[(size_t)q * qcap + idx] = o;
                     // lower end = upper end - 2 (s_r s_q B_q + c), one more allowance for the f32 evaluation
-                    qlo[(size_t)q * qcap + idx] = bits_f32(cnd[j].x) - 2.0f * fmaf(s_r[j], hwf[q], c_abs) - 2e-6f;
+                    // (an upper end from the sample launch's record was rounded UP to bf16, by at most 2^-7 of its magnitude: the lower end
+                    // steps down by as much -- cnd.w says so)
+                    const float up = bits_f32(cnd[j].x);
+                    qlo[(size_t)q * qcap + idx] = up - 2.0f * fmaf(s_r[j], hwf[q], c_abs) - 2e-6f - (cnd[j].w ? fabsf(up) * (1.0f / 128.0f) : 0.f);
                 }
             }
         }

@@ -76,6 +76,7 @@ struct crh_index {
     int i8_cooldown = 0;      // ... for this many batches; then it gets ONE more try, and the next overflow rests it again)
     bool i8_suppress = false; // (while such a batch is run again on the bf16 scan)
     int nominate_max = CRH_NOMINATE_INT8;   // crh_index_set_nomination: the most advanced mode the caller allows
+    bool i8_sample_record = true;           // the sample launch records its tiles' upper ends, the pass does not read those tiles again (CODERAG_HIP_I8_SAMPLE_RECORD=0: it does)
     bool i8_sample_auto = true;             // (CODERAG_HIP_I8_SAMPLE set: that many tiles at every size)
     int i8_sample = kI8SampleTiles;         // sample tiles behind the int8 scan's thresholds: 8192 halves the candidates of 4096 for 100 MB more
                                             // sample reads (-22 us per batch on one index, tools/sample_ab.py); CODERAG_HIP_I8_SAMPLE
@@ -105,7 +106,7 @@ struct crh_index {
         int ws_blocks = 0, ws_wave_cap = 0, ws_qcap = 0, ws_seed = 0;
         int64_t ws_mask_tiles = 0;
         float *qn = nullptr, *gmax = nullptr, *tau = nullptr, *qpar = nullptr, *qlo = nullptr;
-        u32x4 *qfrag = nullptr, *qfrag8 = nullptr, *wave_lists = nullptr;
+        u32x4 *qfrag = nullptr, *qfrag8 = nullptr, *wave_lists = nullptr, *shi = nullptr;
         uint32_t *effmask = nullptr;
         u32x2 *qlist = nullptr;
         unsigned long long *skeys = nullptr, *skeys2 = nullptr;
@@ -388,13 +389,13 @@ int i8_sync(crh_index *h, hipStream_t st)
 // PART 1: the sample tiles, 2: the thresholds (one workgroup per query), 3: the pass -- three launches, stream order between them
 template <int PART>
 int launch_scan_i8(crh_index *h, crh_index::Workspace &w, int blocks, hipStream_t st, const uint32_t *mask, int ntiles, int G, int S, int k, float c_abs,
-                   int nq, int wave_cap, int qcap, SearchStatus *stt)
+                   int nq, int wave_cap, int qcap, SearchStatus *stt, u32x4 *shi)
 {
 #define CRH_I8(KS8, RING, QB)                                                                                                          \
     hipLaunchKernelGGL((k_scan_i8<KS8, kI8Waves, RING, QB, PART>), dim3(PART == 2 ? QB * 32 : blocks), dim3(kI8Waves * 64), 0, st, h->x8, h->srow, \
                        h->i8stat, w.qfrag8, w.qpar, mask, ntiles, G, S, reinterpret_cast<uint32_t *>(w.gmax), w.tau, k, c_abs, sqrtf((float)h->dim), \
                        nq, w.wave_lists, wave_cap, stt->qcount, w.qlist, w.qlo, qcap, stt, h->xt,                                               \
-                       h->dtype == CRH_DTYPE_F32 ? h->xf32 : (const float *)nullptr, w.qn, h->xrow)
+                       h->dtype == CRH_DTYPE_F32 ? h->xf32 : (const float *)nullptr, w.qn, h->xrow, PART == 2 ? (u32x4 *)nullptr : shi)
     switch (h->dim) {
     case 384: CRH_I8(12, 12, 2); break;
     case 768: CRH_I8(24, kI8Ring, 2); break;
@@ -479,10 +480,17 @@ int enqueue_batch(crh_index *h, crh_index::Workspace &w, const float *q_dev, int
         // summation orders only -- the copy of an f32 store is quantised from its f32 master, not from the bf16 tiles
         const float c_abs = 1.5e-4f * (h->dim > 768 ? (float)h->dim / 768.f : 1.f) + 1e-5f;
         if (h->profiling && h->profile_whole_scan) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));   // (all three launches of the scan)
-        CRH_TRY(launch_scan_i8<1>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
-        CRH_TRY(launch_scan_i8<2>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        // the sample launch records the upper ends of its tiles' rows and the pass takes those tiles' candidates from the record
+        // instead of reading and multiplying the tiles again (crh_i8.hpp, `shi`; CODERAG_HIP_I8_SAMPLE_RECORD=0: the pass reads every tile)
+        u32x4 *shi = nullptr;
+        if (h->i8_sample_record) {
+            if (!w.shi) CRH_TRY(dev_alloc(&w.shi, (int64_t)kI8SampleTiles * 64 * 4));
+            shi = w.shi;
+        }
+        CRH_TRY(launch_scan_i8<1>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt, shi));
+        CRH_TRY(launch_scan_i8<2>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt, shi));
         if (h->profiling && !h->profile_whole_scan) CRH_HIP(hipEventRecord(h->ev[2 * slot], st));   // (the dominant kernel: the pass)
-        CRH_TRY(launch_scan_i8<3>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt));
+        CRH_TRY(launch_scan_i8<3>(h, w, blocks, st, mask, (int)ntiles, G8, S8, k, c_abs, nq, wave_cap * (kWaves / kI8Waves), qcap, stt, shi));
         if (h->profiling) CRH_HIP(hipEventRecord(h->ev[2 * slot + 1], st));
         // (k_select's margin behind this scan: twice what separates a row's score summed in any order from its canonical score)
         if (h->dtype == CRH_DTYPE_F32)
@@ -721,6 +729,7 @@ int crh_index_create(int dim, int dtype, int64_t capacity_rows, int n_code_cols,
         h->i8 = h->fused_scan && !(e8 && e8[0] == '0');
         if (h->i8) h->qcap = 131072;   // ~21 k candidates per query and 10M Gaussian rows behind the int8 scan (37 k with 4096 sample tiles)
         if (const char *em = getenv("CODERAG_HIP_I8_MIN_ROWS")) h->i8_min_rows = atoll(em);
+        if (const char *er = getenv("CODERAG_HIP_I8_SAMPLE_RECORD")) h->i8_sample_record = !(er[0] == '0');
         if (const char *es = getenv("CODERAG_HIP_I8_SAMPLE")) {
             h->i8_sample = std::max(1024, std::min(kI8SampleTiles, atoi(es)));
             h->i8_sample_auto = false;
@@ -774,6 +783,7 @@ int crh_index_destroy(crh_index *h)
         dev_free(w.qlist);
         dev_free(w.skeys);
         dev_free(w.qfrag8);
+        dev_free(w.shi);
         dev_free(w.qpar);
         dev_free(w.qlo);
         dev_free(w.skeys2);

@@ -950,3 +950,36 @@ def test_the_kept_filter_mask_follows_every_mutation(gpu, policy):
     es, er = orc.cosine_search(x[keep], q, 30, bf16=True, codes=codes[keep], filters=f1)
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32)) and np.array_equal(o2n[keep], np.arange(len(keep)))
     idx.close()
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_the_pass_takes_the_sample_tiles_from_the_sample_launchs_record(gpu, monkeypatch, bf16):
+    """Round 5: the int8 scan's sample launch records the upper ends of its tiles' rows (bf16, rounded up) and the pass takes those
+    tiles' candidates from the record instead of reading and multiplying the tiles a second time; it walks the other tiles only.
+    Same ids and score bits as with the record switched off and as the oracle -- at a size where sample and other tiles mix (S = 3),
+    at one where every tile is a sample tile (the pass reads nothing), under a filter and with sample rows tombstoned."""
+    ffi = _ffi()
+    monkeypatch.setenv("CODERAG_HIP_I8_MIN_ROWS", "0")
+    monkeypatch.setenv("CODERAG_HIP_I8_SAMPLE", "1024")            # 1024 sample tiles at every size
+    rng = np.random.default_rng(91)
+    for n in (100_000, 20_000):                                    # 3125 tiles: S = 3, 53 tiles behind the last sample block; 625 tiles: all sampled
+        x = _corpus(n, 92 + n)
+        codes = rng.integers(0, 3, (n, 1)).astype(np.int32)
+        q = _corpus(64, 93)
+        out = {}
+        for rec in ("1", "0"):
+            monkeypatch.setenv("CODERAG_HIP_I8_SAMPLE_RECORD", rec)
+            idx = ffi.Index(D, ffi.DTYPE_BF16 if bf16 else ffi.DTYPE_F32, capacity_rows=n, n_code_cols=1)
+            idx.append(x, codes)
+            assert idx.nomination() == ffi.NOMINATE_INT8
+            dead = np.arange(0, n, 96, dtype=np.int64)             # rows 0, 96, 192, ...: every third tile's first row -- sample tiles among them
+            idx.tombstone(dead)
+            alive = np.ones(n, np.uint8)
+            alive[dead] = 0
+            a = _check(idx, ffi, x, q, 100, bf16, alive=alive)
+            b = _check(idx, ffi, x, q[:5], 10, bf16, filters=[(0, 1)], alive=alive, codes=codes, ofilters=[(0, 1)])
+            assert idx.stats()["fallback_used"] == 0
+            out[rec] = (a, b)
+            idx.close()
+        for (s1, r1), (s0, r0) in zip(out["1"], out["0"]):
+            assert np.array_equal(r1, r0) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
