@@ -4,7 +4,7 @@
 Survey-container-only (needs `transformers`; never imported by the package or the tests).  The HF model is built
 locally from a RobertaConfig (no hub access) with is_decoder=False and a 2-D attention mask -- the semantics the
 reference's 3-D mask had under transformers 4.x -- and loaded with the seeded weights of
-oracle.encoder.random_weights.  Writes tests/golden/encoder_{tiny,base,hfinit}.npz: config, seed, ids and the expected
+oracle.encoder.random_weights.  Writes tests/golden/encoder_{tiny,base,hfinit,hfln}.npz: config, seed, ids and the expected
 sentence embeddings (HF fp32).  Weights are NOT stored: they are regenerated from the seed.
 """
 import os
@@ -66,3 +66,6 @@ if __name__ == "__main__":
     # the same geometry with HF-init-like statistics (N(0, 0.02^2) matrices, zero biases, unit LayerNorm): real checkpoints sit
     # between this and the deliberately sharp "base" weights
     case("hfinit", enc.EncoderConfig(), 29, [128, 33, 77, 200], 208, init="hf")
+    # between the two (round 5): HF-init matrices with the sharp fixture's biases and LayerNorm gains / biases
+    if "hfln" in sys.argv[1:] or not sys.argv[1:]:
+        case("hfln", enc.EncoderConfig(), 31, [96, 40, 160, 12], 160, init="hf_ln")

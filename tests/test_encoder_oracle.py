@@ -20,10 +20,14 @@ def load_case(name):
     return cfg, int(z["seed"]), z["ids"], z["sent"]
 
 
-@pytest.mark.parametrize("name", ["tiny", "base"])
+# (hfinit / hfln: the same geometry on HF-init statistics and on HF-init matrices with the sharp fixture's biases and LayerNorm
+# parameters -- the fixtures name their weight statistic)
+@pytest.mark.parametrize("name", ["tiny", "base", "hfinit", "hfln"])
 def test_oracle_matches_hf_fixture(name):
     cfg, seed, ids, sent = load_case(name)
-    got = orc.forward(orc.random_weights(cfg, seed), cfg, ids)
+    z = np.load(os.path.join(GOLD, f"encoder_{name}.npz"))
+    init = str(z["init"]) if "init" in z.files else "sharp"
+    got = orc.forward(orc.random_weights(cfg, seed, init=init), cfg, ids)
     assert np.abs(got - sent).max() < 3e-5          # HF RobertaModel fp32 (eager attention) on the same weights
 
 
