@@ -324,7 +324,7 @@ def test_embed_ln_and_pool(gpu):
 ENCODER_TOL = {"tiny": ((0.9999, 1e-2), (0.9995, 3e-2)),
                "base": ((0.9993, 4e-2), (0.997, 8e-2)),
                "hfinit": ((0.99995, 1e-2), (0.9999, 1.5e-2)),
-               "hfln": ((0.9999, 1.2e-2), (0.9998, 2e-2))}      # HF-init matrices, the sharp fixture's biases and LayerNorm parameters (round 5)
+               "hfln": ((0.99995, 1e-2), (0.9999, 1.5e-2))}      # HF-init matrices, the sharp fixture's biases and LayerNorm parameters (round 5)
 
 
 @pytest.mark.parametrize("form", ["two LayerNorm kernels", "ln_fold", "residual_f32"])
