@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
         stage(R_WH0, B);
         extra_load(false);
         if (last && !(DBG & 2)) {
-            if (EPI == 5) {   // one column per lane (2 registers; the epilogue hands a fragment round by ds_bpermute when it needs it)
+            if (EPI == 5) {   // one column per lane (2 registers; the epilogue spreads them through a 512-byte LDS table)
                 b_lin = bias[n0 + wc * 64 + lane];
                 g_lin = rstats != nullptr ? aux0[n0 + wc * 64 + lane] : 1.0f;
             } else {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_pp(const bf16_t *__restrict
             // ---- epilogue 5 (header comment): out = bf16(acc + bias + h), h = the residual, normalised on the fly when rstats is given;
             // statistics of the rounded outputs per (row, 32-column slot).  Registers are what bounds this epilogue (the 128
             // accumulators stay live while it runs): bias and gain live lane-linear in one register each and a 4-column fragment
-            // is fetched by ds_bpermute per (q, nt); the residual rows and their statistics come two m-tiles at a time, one step ahead.
+            // is read from a small LDS table per (q, nt); the residual rows and their statistics come in two batches of four m-tiles.
             const bool res_ln = rstats != nullptr;
             // (lane-derived values made opaque HERE: otherwise every address this block derives from them is hoisted out of the
             // tile loop as an invariant, lives across the main loop and is spilled there -- the k_gemm_pp header's warning)
